@@ -1,0 +1,16 @@
+"""paella_amd -- the sampling hot path of dome272/Paella, built MI355X-first.
+
+Public surface (mirrors the reference's Python API):
+    Paella / DenoiseUNet      reference src/modules.py:109
+    VQModel                   reference src/vqgan.py:45
+    sample                    reference src/utils.py:35
+    sample_distributed        reference src_distributed/utils.py:97
+    replace_attention_layers  reference utils/alter_attention.py:45
+Everything executes through libpaella_hip.so (hand-written HIP for gfx950, C ABI in include/paella_hip.h).
+"""
+from .modules import CondCache, DenoiseUNet, Paella, replace_attention_layers
+from .sampling import sample, sample_distributed
+from .vqgan import VectorQuantize, VQModel
+
+__all__ = ["Paella", "DenoiseUNet", "CondCache", "VQModel", "VectorQuantize", "sample", "sample_distributed",
+           "replace_attention_layers"]

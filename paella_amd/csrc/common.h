@@ -1,0 +1,177 @@
+// Shared device/host declarations for the Paella gfx950 kernels.
+// Everything here is fp32 / int64, NHWC ("position-major") activations:
+// an activation is a row-major matrix [rows = B*h*w, channels].
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define PAELLA_OK 0
+#define PAELLA_ERR_ARG -1
+#define PAELLA_ERR_HIP -2
+#define PAELLA_ERR_WORKSPACE -3
+#define PAELLA_ERR_STATE -4
+
+void paella_set_error(const char* fmt, ...);
+
+#define HIP_CHECK_RET(expr)                                                          \
+    do {                                                                             \
+        hipError_t _e = (expr);                                                      \
+        if (_e != hipSuccess) {                                                      \
+            paella_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr,           \
+                             hipGetErrorString(_e));                                 \
+            return PAELLA_ERR_HIP;                                                   \
+        }                                                                            \
+    } while (0)
+
+#define LAUNCH_CHECK_RET()                                                           \
+    do {                                                                             \
+        hipError_t _e = hipGetLastError();                                           \
+        if (_e != hipSuccess) {                                                      \
+            paella_set_error("%s:%d: kernel launch -> %s", __FILE__, __LINE__,       \
+                             hipGetErrorString(_e));                                 \
+            return PAELLA_ERR_HIP;                                                   \
+        }                                                                            \
+    } while (0)
+
+// ---------------------------------------------------------------------------
+// GEMM epilogue description (shared by the GEMM kernel and the split-K reducer)
+// ---------------------------------------------------------------------------
+enum { STORE_PLAIN = 0, STORE_D2S = 1, STORE_PIXSHUF_NCHW = 2 };
+enum { ACT_NONE = 0, ACT_GELU = 1 };
+
+struct Epilogue {
+    const float* bias;      // [N] or null
+    int act;                // ACT_*
+    float alpha;            // v *= alpha after the activation (VQGAN gamma[5]); 1 otherwise
+    const float* residual;  // [M, ldr] or null; added after alpha
+    int ldr;
+    const float* ts;        // or null: v = v*(1+ts[b*ts_stride + n]) + ts[b*ts_stride + N + n]
+    int ts_stride;          // floats between consecutive samples in ts
+    int rows_per_sample;    // rows of this matrix per batch sample (for ts)
+    int store_mode;         // STORE_*
+    int sH, sW, sC;         // STORE_D2S / PIXSHUF: source grid (rows m=(b,y,x)), channels per segment
+    int py, px;             // STORE_D2S: extra output offset (transposed-conv phase)
+    int n_seg_x;            // STORE_D2S: segments along n are (dy,dx) with dx in [0,n_seg_x); 2 for k2s2, 1 for a phase
+    int remap_in, remap_out, remap_off;  // STORE_PLAIN, remap_in > 0: out row = (m/remap_in)*remap_out + m%remap_in + remap_off
+};
+
+static inline Epilogue make_epilogue() {
+    Epilogue e;
+    e.bias = nullptr; e.act = ACT_NONE; e.alpha = 1.f; e.residual = nullptr; e.ldr = 0;
+    e.ts = nullptr; e.ts_stride = 0; e.rows_per_sample = 1; e.store_mode = STORE_PLAIN;
+    e.sH = e.sW = e.sC = 0; e.py = e.px = 0; e.n_seg_x = 2; e.remap_in = e.remap_out = e.remap_off = 0;
+    return e;
+}
+
+struct GemmArgs {
+    const float* A; int lda;   // [M, K] row-major
+    const float* W; int ldw;   // [N, K] row-major (torch Linear layout)
+    float* C; int ldc;         // [M, N]
+    int M, N, K;
+    // optional A-operand prologue (GlobalResponseNorm apply): a' = a*scale[b][k] + shift[k]
+    const float* a_scale;      // [samples, K] or null
+    const float* a_shift;      // [K]
+    int a_rows_per_sample;
+    Epilogue ep;
+};
+
+// Launchers (each returns PAELLA_OK or an error code; all work is enqueued on `stream`).
+// `ws` is scratch for split-K partial slabs; pass ws_bytes = 0 to forbid split-K.
+int launch_gemm(const GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t stream);
+// Forces a specific tile config / split (for the autotuner and tests). cfg < 0 -> heuristic.
+int launch_gemm_cfg(const GemmArgs& g, int cfg, int splitk, void* ws, size_t ws_bytes, hipStream_t stream);
+size_t gemm_splitk_ws_bytes(int M, int N, int K);
+
+// LayerNorm over the channel dimension of [rows, C]; no learned affine (eps 1e-6),
+// optional scalar affine y = ln(x)*(1+g0)+g1 (VQGAN), optional space-to-depth gather:
+// s2d != 0: output row (b,y',x') segment (dy,dx) <- input row (b,2y'+dy,2x'+dx); out is [rows/4, 4C].
+int launch_layernorm(const float* x, float* y, int64_t rows, int C, float eps, float g_mul, float g_add,
+                     int s2d, int H, int W, hipStream_t stream);
+
+// UNet ResBlock front half: depthwise 3x3 (zero pad) + bias, then LayerNorm over channels.
+// skip != null: grouped 2C->C variant over cat([x, skip]) (reference src/modules.py:46,57).
+int launch_dwconv_ln(const float* x, const float* skip, const float* w, const float* bias, float* y,
+                     int B, int H, int W, int C, float eps, hipStream_t stream);
+// VQGAN ResBlock depthwise half: y = x + (dw3x3_replicate(xt) + bias) * gamma2.
+int launch_dwconv_res(const float* x, const float* xt, const float* w, const float* bias, float* y,
+                      int B, int H, int W, int C, float gamma2, hipStream_t stream);
+
+// GlobalResponseNorm statistics: scale[b][c] = 1 + gamma[c] * Gx[b][c] / (mean_c Gx[b][:] + 1e-6),
+// Gx[b][c] = sqrt(sum over the sample's rows of g[row][c]^2).
+int launch_grn_scale(const float* g, const float* gamma, float* scale, float* tmp_gx, int B,
+                     int rows_per_sample, int C, hipStream_t stream);
+
+// Token embedding gather + LayerNorm(c_in) + PixelUnshuffle(p): tokens int64 [B,H,W] ->
+// out [B*(H/p)*(W/p), c_in*p*p] with channel index c*p*p + dy*p + dx.
+int launch_embed_ln_unshuffle(const int64_t* tokens, const float* table, float* out, int B, int H, int W,
+                              int c_in, int patch, int num_labels, float eps, hipStream_t stream);
+
+// Sinusoidal timestep embedding + every TimestepBlock mapper in one launch.
+// r [B], freqs [c_r/2] (host-computed, torch order), Wcat [total, c_r], bcat [total] -> ts [B, total].
+int launch_timestep(const float* r, const float* freqs, const float* Wcat, const float* bcat, float* ts,
+                    int B, int c_r, int total, float max_positions, float* r_embed_out, hipStream_t stream);
+// x = x*(1+a)+b with [a|b] = ts[b][0:2C] (standalone TimestepBlock).
+int launch_scale_shift(float* x, const float* ts, int ts_stride, int64_t rows, int rows_per_sample, int C,
+                       hipStream_t stream);
+
+int launch_silu(const float* x, float* y, int64_t n, hipStream_t stream);
+int launch_copy_rows(const float* src, int lds, float* dst, int ldd, int64_t rows, int cols, hipStream_t stream);
+
+// Attention over [self keys | conditioning keys] (reference src/modules.py:7-19,65-79;
+// utils/alter_attention.py:4-43). q/k/v are column blocks of row-major buffers.
+struct AttnArgs {
+    const float* q; int ldq;          // [B*Lq, ...], head h at columns h*D
+    const float* k_self; const float* v_self; int ld_self;   // [B*Lself, ...] or null when Lself == 0
+    const float* k_cond; const float* v_cond; int ld_cond;   // [B*Lcond, ...]
+    float* out; int ldo;              // [B*Lq, nhead*D]
+    int B, nhead, D, Lq, Lself, Lcond;
+    float scale;
+    const float* key_weights;         // [n_kw] post-softmax multipliers for the LAST n_kw keys, or null
+    int n_kw;
+};
+int launch_attention(const AttnArgs& a, hipStream_t stream);
+
+// Sampling tail (reference src/utils.py:45-54): CFG mix, temperature, softmax, categorical draw, renoise.
+struct TailArgs {
+    const float* logits_c; const float* logits_u;  // [rows, L]; logits_u null -> no CFG
+    int64_t rows; int L;
+    float cfg, one_minus_cfg, temperature;
+    int mode;                     // 0 = categorical, 1 = argmax (T=0 extension)
+    const float* noise_q;         // [rows, L] Exp(1) noise (parity mode) or null -> Philox
+    uint64_t seed; uint64_t offset;
+    const int64_t* init_noise;    // renoise source or null (no renoise)
+    const float* mask_u;          // [rows] U[0,1) (parity mode) or null -> Philox
+    float t_next;                 // uniform over the batch inside sample()
+    int64_t* tokens_out;          // [rows]
+    int64_t* sampled_out;         // [rows] pre-renoise draw (optional, may be null)
+};
+int launch_sample_tail(const TailArgs& a, hipStream_t stream);
+
+// add_noise (reference src/modules.py:277-283)
+int launch_add_noise(const int64_t* x, const float* t, const int64_t* mask_in, const int64_t* random_x,
+                     const float* rand_u, uint64_t seed, uint64_t offset, int num_labels, int B,
+                     int64_t per_sample, int64_t* x_out, int64_t* mask_out, hipStream_t stream);
+
+// VQGAN helpers
+int launch_codebook_gather(const int64_t* idx, const float* codebook, float* out, int64_t rows, int D, int K,
+                           float scale, hipStream_t stream);
+// Transposed conv k4 s2 p1 phase gather: for phase (py,px) builds A[rows_in, 4*C] from x [B,H,W,C]
+int launch_convT4_gather(const float* x, float* out, int B, int H, int W, int C, int py, int px, hipStream_t stream);
+// Conv k4 s2 p1 im2col: x [B,H,W,C] -> out [B*(H/2)*(W/2), 16*C], k index (ky,kx,c)
+int launch_conv4s2_im2col(const float* x, float* out, int B, int H, int W, int C, hipStream_t stream);
+// image NCHW [B,3,Hp,Wp] -> PixelUnshuffle(2) NHWC [B*(Hp/2)*(Wp/2), 12], channel c*4+dy*2+dx
+int launch_img_unshuffle(const float* img, float* out, int B, int C, int Hp, int Wp, hipStream_t stream);
+// nearest codebook row (squared L2, first minimum wins)
+int launch_vq_nearest(const float* x, const float* codebook, int64_t* idx, float* qe, int64_t rows, int D, int K,
+                      hipStream_t stream);
+// y[row][c] = x[row][c]*scale[c] + shift[c]  (BatchNorm eval) and NHWC -> NCHW transposes
+int launch_affine_cols(const float* x, const float* scale, const float* shift, float* y, int64_t rows, int C,
+                       hipStream_t stream);
+// y = divide ? x / scale : x * scale, with the layout change
+int launch_nhwc_to_nchw(const float* x, float* y, int B, int HW, int C, float scale, int divide, hipStream_t stream);
+int launch_nchw_to_nhwc(const float* x, float* y, int B, int HW, int C, float scale, int divide, hipStream_t stream);
+// generic <=5-d permute-copy used once per tensor when weights are loaded
+int launch_permute(const float* src, float* dst, const int64_t* shape, const int* perm, int ndim, hipStream_t stream);

@@ -1,0 +1,486 @@
+// HBM-bound kernels of the Paella hot path for gfx950: LayerNorm, depthwise 3x3 conv (+LN), GRN statistics,
+// token-embedding gather, timestep embedding, layout shuffles.  All activations are NHWC fp32
+// ([rows = B*h*w, C] row-major), so every wave streams whole channel rows with 16-byte lanes and all
+// per-position reductions are wave64 shuffles (no LDS, no barriers) -- one wave per position.
+#include "common.h"
+
+#define WAVES_PER_BLOCK 4
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ float hsum4(f32x4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
+
+// Normalise NV float4 per lane held in registers: two-pass mean / biased variance (torch LayerNorm semantics).
+template <int NV>
+__device__ __forceinline__ void ln_regs(f32x4 (&v)[NV], int C4, int lane, int C, float eps, float mul, float add) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (lane + i * 64 < C4) s += hsum4(v[i]);
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (lane + i * 64 < C4) {
+            f32x4 d = v[i] - mean;
+            d = d * d;
+            q += hsum4(d);
+        }
+    const float var = wave_sum(q) / (float)C;
+    const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = (v[i] - mean) * rstd * mul + add;
+}
+
+// ---------------------------------------------------------------------------
+// LayerNorm (reference src/modules.py:22-27 LayerNorm2d; src/vqgan.py:35-39 norm + gamma affine)
+// ---------------------------------------------------------------------------
+template <int NV>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void layernorm_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                        int64_t rows, int C, float eps, float g_mul,
+                                                                        float g_add, int s2d, int H, int W) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int C4 = C >> 2;
+    f32x4 v[NV];
+    const float* xr = x + row * C;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c4 = lane + i * 64;
+        v[i] = c4 < C4 ? ld4(xr + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    ln_regs<NV>(v, C4, lane, C, eps, g_mul, g_add);
+    float* yr;
+    if (s2d) {
+        const int64_t hw = (int64_t)H * W;
+        const int64_t b = row / hw;
+        const int rem = (int)(row - b * hw);
+        const int yy = rem / W, xx = rem - yy * W;
+        const int64_t orow = (b * (H >> 1) + (yy >> 1)) * (W >> 1) + (xx >> 1);
+        yr = y + orow * (4 * (int64_t)C) + ((yy & 1) * 2 + (xx & 1)) * C;
+    } else {
+        yr = y + row * C;
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c4 = lane + i * 64;
+        if (c4 < C4) st4(yr + c4 * 4, v[i]);
+    }
+}
+
+#define DISPATCH_NV(C4, ...)                                                       \
+    do {                                                                           \
+        const int _nv = ((C4) + 63) / 64;                                          \
+        if (_nv <= 1) { constexpr int NV = 1; __VA_ARGS__; }                       \
+        else if (_nv <= 2) { constexpr int NV = 2; __VA_ARGS__; }                  \
+        else if (_nv <= 3) { constexpr int NV = 3; __VA_ARGS__; }                  \
+        else if (_nv <= 5) { constexpr int NV = 5; __VA_ARGS__; }                  \
+        else if (_nv <= 8) { constexpr int NV = 8; __VA_ARGS__; }                  \
+        else if (_nv <= 16) { constexpr int NV = 16; __VA_ARGS__; }                \
+        else { paella_set_error("channel count %d too large", (C4) * 4); return PAELLA_ERR_ARG; } \
+    } while (0)
+
+int launch_layernorm(const float* x, float* y, int64_t rows, int C, float eps, float g_mul, float g_add, int s2d,
+                     int H, int W, hipStream_t st) {
+    if (rows <= 0) return PAELLA_OK;
+    if (C & 3) { paella_set_error("layernorm: C %% 4 != 0 (C=%d)", C); return PAELLA_ERR_ARG; }
+    if (s2d && ((H & 1) || (W & 1))) { paella_set_error("layernorm s2d: odd grid %dx%d", H, W); return PAELLA_ERR_ARG; }
+    const unsigned blocks = (unsigned)((rows + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+    DISPATCH_NV(C >> 2, hipLaunchKernelGGL((layernorm_kernel<NV>), dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, st, x, y,
+                                           rows, C, eps, g_mul, g_add, s2d, H, W));
+    LAUNCH_CHECK_RET();
+    return PAELLA_OK;
+}
+
+// ---------------------------------------------------------------------------
+// UNet ResBlock front half (reference src/modules.py:46-47,55-58):
+//   depthwise Conv2d(k=3, zero padding, groups=C) + bias -> LayerNorm2d(C)
+// weights are repacked [tap][C] (tap = ky*3+kx); the skip variant (Conv2d(2C->C, groups=C) over
+// cat([x, skip])) is repacked [j][tap][C]: output channel g reads concatenated channels 2g+j.
+// ---------------------------------------------------------------------------
+template <int NV, bool SKIP>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void dwconv_ln_kernel(const float* __restrict__ x,
+                                                                        const float* __restrict__ skip,
+                                                                        const float* __restrict__ w,
+                                                                        const float* __restrict__ bias,
+                                                                        float* __restrict__ y, int B, int H, int W, int C,
+                                                                        float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t pos = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    const int64_t total = (int64_t)B * H * W;
+    if (pos >= total) return;
+    const int C4 = C >> 2;
+    const int xx = (int)(pos % W);
+    const int yy = (int)((pos / W) % H);
+    f32x4 acc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c4 = lane + i * 64;
+        acc[i] = c4 < C4 ? ld4(bias + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int sy = yy + ky - 1;
+        if (sy < 0 || sy >= H) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int sx = xx + kx - 1;
+            if (sx < 0 || sx >= W) continue;
+            const int64_t npos = pos + (int64_t)(ky - 1) * W + (kx - 1);
+            const int tap = ky * 3 + kx;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c4 = lane + i * 64;
+                if (c4 >= C4) continue;
+                if (!SKIP) {
+                    acc[i] += ld4(x + npos * C + c4 * 4) * ld4(w + tap * C + c4 * 4);
+                } else {
+                    // out channels g..g+3 (g = 4*c4) read cat channels 2g..2g+7
+                    const int cc = 8 * c4;
+                    const float* src = cc < C ? (x + npos * C + cc) : (skip + npos * C + (cc - C));
+                    const f32x4 e0 = ld4(src), e1 = ld4(src + 4);
+                    const f32x4 w0 = ld4(w + tap * C + c4 * 4);
+                    const f32x4 w1 = ld4(w + (9 + tap) * C + c4 * 4);
+                    acc[i][0] += e0[0] * w0[0] + e0[1] * w1[0];
+                    acc[i][1] += e0[2] * w0[1] + e0[3] * w1[1];
+                    acc[i][2] += e1[0] * w0[2] + e1[1] * w1[2];
+                    acc[i][3] += e1[2] * w0[3] + e1[3] * w1[3];
+                }
+            }
+        }
+    }
+    ln_regs<NV>(acc, C4, lane, C, eps, 1.0f, 0.0f);
+    float* yr = y + pos * C;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c4 = lane + i * 64;
+        if (c4 < C4) st4(yr + c4 * 4, acc[i]);
+    }
+}
+
+int launch_dwconv_ln(const float* x, const float* skip, const float* w, const float* bias, float* y, int B, int H,
+                     int W, int C, float eps, hipStream_t st) {
+    const int64_t total = (int64_t)B * H * W;
+    if (total <= 0) return PAELLA_OK;
+    if ((C & 3) || (skip && (C & 7))) { paella_set_error("dwconv_ln: bad channel count %d", C); return PAELLA_ERR_ARG; }
+    const unsigned blocks = (unsigned)((total + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+    if (skip)
+        DISPATCH_NV(C >> 2, hipLaunchKernelGGL((dwconv_ln_kernel<NV, true>), dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, st,
+                                               x, skip, w, bias, y, B, H, W, C, eps));
+    else
+        DISPATCH_NV(C >> 2, hipLaunchKernelGGL((dwconv_ln_kernel<NV, false>), dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, st,
+                                               x, skip, w, bias, y, B, H, W, C, eps));
+    LAUNCH_CHECK_RET();
+    return PAELLA_OK;
+}
+
+// ---------------------------------------------------------------------------
+// VQGAN ResBlock depthwise half (reference src/vqgan.py:11-14,38):
+//   y = x + (Conv2d(k=3, groups=C)(ReplicationPad2d(1)(xt)) + bias) * gamma2
+// ---------------------------------------------------------------------------
+template <int NV>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void dwconv_res_kernel(const float* __restrict__ x,
+                                                                         const float* __restrict__ xt,
+                                                                         const float* __restrict__ w,
+                                                                         const float* __restrict__ bias,
+                                                                         float* __restrict__ y, int B, int H, int W, int C,
+                                                                         float gamma2) {
+    const int lane = threadIdx.x & 63;
+    const int64_t pos = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    const int64_t total = (int64_t)B * H * W;
+    if (pos >= total) return;
+    const int C4 = C >> 2;
+    const int xx = (int)(pos % W);
+    const int yy = (int)((pos / W) % H);
+    const int64_t base = pos - (int64_t)yy * W - xx;  // (b, 0, 0)
+    f32x4 acc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c4 = lane + i * 64;
+        acc[i] = c4 < C4 ? ld4(bias + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int sy = min(max(yy + ky - 1, 0), H - 1);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int sx = min(max(xx + kx - 1, 0), W - 1);
+            const int64_t npos = base + (int64_t)sy * W + sx;
+            const int tap = ky * 3 + kx;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c4 = lane + i * 64;
+                if (c4 < C4) acc[i] += ld4(xt + npos * C + c4 * 4) * ld4(w + tap * C + c4 * 4);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c4 = lane + i * 64;
+        if (c4 < C4) st4(y + pos * C + c4 * 4, ld4(x + pos * C + c4 * 4) + acc[i] * gamma2);
+    }
+}
+
+int launch_dwconv_res(const float* x, const float* xt, const float* w, const float* bias, float* y, int B, int H,
+                      int W, int C, float gamma2, hipStream_t st) {
+    const int64_t total = (int64_t)B * H * W;
+    if (total <= 0) return PAELLA_OK;
+    if (C & 3) { paella_set_error("dwconv_res: C %% 4 != 0"); return PAELLA_ERR_ARG; }
+    const unsigned blocks = (unsigned)((total + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+    DISPATCH_NV(C >> 2, hipLaunchKernelGGL((dwconv_res_kernel<NV>), dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, st, x, xt, w,
+                                           bias, y, B, H, W, C, gamma2));
+    LAUNCH_CHECK_RET();
+    return PAELLA_OK;
+}
+
+// ---------------------------------------------------------------------------
+// GlobalResponseNorm statistics (reference src/modules.py:37-40).  The apply step
+// gamma*(x*Nx)+beta+x == x*(1+gamma*Nx)+beta is folded into the next GEMM's A-operand load.
+// Deterministic: fixed-order partial sums, no atomics.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void grn_sumsq_kernel(const float* __restrict__ g, float* __restrict__ gx, int rows_per_sample,
+                                                        int C) {
+    // block = 64 channels x 4 row groups; grid = (ceil(C/64), B)
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const int b = blockIdx.y;
+    float s = 0.f;
+    if (c < C) {
+        const float* p = g + ((size_t)b * rows_per_sample) * C + c;
+        for (int r = rg; r < rows_per_sample; r += 4) {
+            const float v = p[(size_t)r * C];
+            s += v * v;
+        }
+    }
+    red[rg][cl] = s;
+    __syncthreads();
+    if (rg == 0 && c < C) gx[(size_t)b * C + c] = sqrtf((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]));
+}
+
+__global__ __launch_bounds__(256) void grn_finalize_kernel(const float* __restrict__ gx, const float* __restrict__ gamma,
+                                                           float* __restrict__ scale, int C) {
+    __shared__ float red[256];
+    const int b = blockIdx.x;
+    const float* p = gx + (size_t)b * C;
+    float s = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) s += p[c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    const float denom = red[0] / (float)C + 1e-6f;
+    for (int c = threadIdx.x; c < C; c += 256) scale[(size_t)b * C + c] = 1.0f + gamma[c] * (p[c] / denom);
+}
+
+int launch_grn_scale(const float* g, const float* gamma, float* scale, float* tmp_gx, int B, int rows_per_sample,
+                     int C, hipStream_t st) {
+    if (B <= 0) return PAELLA_OK;
+    hipLaunchKernelGGL(grn_sumsq_kernel, dim3((C + 63) / 64, B), dim3(256), 0, st, g, tmp_gx, rows_per_sample, C);
+    LAUNCH_CHECK_RET();
+    hipLaunchKernelGGL(grn_finalize_kernel, dim3(B), dim3(256), 0, st, tmp_gx, gamma, scale, C);
+    LAUNCH_CHECK_RET();
+    return PAELLA_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Token embedding + LayerNorm + PixelUnshuffle (reference src/modules.py:126-131,271):
+// one wave per output position (= patch x patch tokens); output channel = c*p*p + dy*p + dx.
+// ---------------------------------------------------------------------------
+template <int P>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void embed_ln_unshuffle_kernel(const int64_t* __restrict__ tokens,
+                                                                                 const float* __restrict__ table,
+                                                                                 float* __restrict__ out, int B, int H,
+                                                                                 int W, int c_in, int num_labels, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int Ho = H / P, Wo = W / P;
+    const int64_t opos = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    const int64_t total = (int64_t)B * Ho * Wo;
+    if (opos >= total) return;
+    const int ox = (int)(opos % Wo);
+    const int oy = (int)((opos / Wo) % Ho);
+    const int64_t b = opos / ((int64_t)Ho * Wo);
+    const int C4 = c_in >> 2;
+    float* orow = out + opos * ((int64_t)c_in * P * P);
+    // statistics per token (full row; the 8 MB table is L2/MALL resident), then the normalised
+    // values are written channel-interleaved so the p*p tokens of a patch fill contiguous floats
+#pragma unroll
+    for (int t = 0; t < P * P; ++t) {
+        const int dy = t / P, dx = t % P;
+        int64_t tok = tokens[(b * H + (oy * P + dy)) * W + (ox * P + dx)];
+        tok = tok < 0 ? 0 : (tok >= num_labels ? num_labels - 1 : tok);
+        const float* row = table + tok * c_in;
+        float s = 0.f;
+        for (int c4 = lane; c4 < C4; c4 += 64) s += hsum4(ld4(row + c4 * 4));
+        const float mean = wave_sum(s) / (float)c_in;
+        float q = 0.f;
+        for (int c4 = lane; c4 < C4; c4 += 64) {
+            f32x4 d = ld4(row + c4 * 4) - mean;
+            d = d * d;
+            q += hsum4(d);
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)c_in + eps);
+        for (int c4 = lane; c4 < C4; c4 += 64) {
+            const f32x4 n = (ld4(row + c4 * 4) - mean) * rstd;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) orow[(c4 * 4 + e) * (P * P) + t] = n[e];
+        }
+    }
+}
+
+int launch_embed_ln_unshuffle(const int64_t* tokens, const float* table, float* out, int B, int H, int W, int c_in,
+                              int patch, int num_labels, float eps, hipStream_t st) {
+    if (c_in & 3) { paella_set_error("embed: c_in %% 4 != 0"); return PAELLA_ERR_ARG; }
+    if (patch < 1 || patch > 2 || (H % patch) || (W % patch)) {
+        paella_set_error("embed: unsupported patch_size %d for grid %dx%d (supported: 1, 2)", patch, H, W);
+        return PAELLA_ERR_ARG;
+    }
+    const int64_t total = (int64_t)B * (H / patch) * (W / patch);
+    if (total <= 0) return PAELLA_OK;
+    const unsigned blocks = (unsigned)((total + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+    if (patch == 2)
+        hipLaunchKernelGGL((embed_ln_unshuffle_kernel<2>), dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, st, tokens, table, out,
+                           B, H, W, c_in, num_labels, eps);
+    else
+        hipLaunchKernelGGL((embed_ln_unshuffle_kernel<1>), dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, st, tokens, table, out,
+                           B, H, W, c_in, num_labels, eps);
+    LAUNCH_CHECK_RET();
+    return PAELLA_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Timestep embedding (reference src/modules.py:212-221) + all TimestepBlock mappers (:99-106) in one launch.
+// freqs[k] = exp(-k*log(max_positions)/(half-1)) is computed on the host with torch so the sin/cos
+// arguments are bit-identical to the reference's.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void timestep_kernel(const float* __restrict__ r, const float* __restrict__ freqs,
+                                                       const float* __restrict__ Wcat, const float* __restrict__ bcat,
+                                                       float* __restrict__ ts, int c_r, int total, float max_positions,
+                                                       float* __restrict__ r_embed_out) {
+    extern __shared__ float emb[];
+    const int b = blockIdx.y;
+    const int half = c_r >> 1;
+    const float rr = r[b] * max_positions;
+    for (int k = threadIdx.x; k < c_r; k += 256) {
+        float v = 0.f;
+        if (k < half) v = sinf(rr * freqs[k]);
+        else if (k < 2 * half) v = cosf(rr * freqs[k - half]);
+        emb[k] = v;
+        if (r_embed_out && blockIdx.x == 0) r_embed_out[(size_t)b * c_r + k] = v;
+    }
+    __syncthreads();
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= total) return;
+    const float* w = Wcat + (size_t)o * c_r;
+    float acc = 0.f;
+    for (int k = 0; k < c_r; ++k) acc += emb[k] * w[k];
+    ts[(size_t)b * total + o] = acc + bcat[o];
+}
+
+int launch_timestep(const float* r, const float* freqs, const float* Wcat, const float* bcat, float* ts, int B,
+                    int c_r, int total, float max_positions, float* r_embed_out, hipStream_t st) {
+    if (B <= 0) return PAELLA_OK;
+    int gx = (total + 255) / 256;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(timestep_kernel, dim3(gx, B), dim3(256), c_r * sizeof(float), st, r, freqs, Wcat, bcat, ts, c_r,
+                       total, max_positions, r_embed_out);
+    LAUNCH_CHECK_RET();
+    return PAELLA_OK;
+}
+
+__global__ __launch_bounds__(256) void scale_shift_kernel(float* __restrict__ x, const float* __restrict__ ts, int ts_stride,
+                                                          int64_t rows, int rows_per_sample, int C) {
+    const int C4 = C >> 2;
+    const int64_t total = rows * C4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / C4;
+        const int c = (int)(i - row * C4) * 4;
+        const float* t = ts + (row / rows_per_sample) * ts_stride;
+        const f32x4 v = ld4(x + row * C + c);
+        st4(x + row * C + c, v * (1.0f + ld4(t + c)) + ld4(t + C + c));
+    }
+}
+
+int launch_scale_shift(float* x, const float* ts, int ts_stride, int64_t rows, int rows_per_sample, int C,
+                       hipStream_t st) {
+    if (rows <= 0) return PAELLA_OK;
+    if (C & 3) { paella_set_error("scale_shift: C %% 4 != 0"); return PAELLA_ERR_ARG; }
+    int64_t blocks = (rows * (C >> 2) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(scale_shift_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, ts, ts_stride, rows, rows_per_sample, C);
+    LAUNCH_CHECK_RET();
+    return PAELLA_OK;
+}
+
+__global__ __launch_bounds__(256) void silu_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float v = x[i];
+        y[i] = v / (1.0f + expf(-v));
+    }
+}
+int launch_silu(const float* x, float* y, int64_t n, hipStream_t st) {
+    if (n <= 0) return PAELLA_OK;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(silu_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, y, n);
+    LAUNCH_CHECK_RET();
+    return PAELLA_OK;
+}
+
+__global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict__ src, int lds_, float* __restrict__ dst, int ldd,
+                                                        int64_t rows, int cols) {
+    const int64_t total = rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / cols;
+        const int c = (int)(i - r * cols);
+        dst[r * ldd + c] = src[r * lds_ + c];
+    }
+}
+int launch_copy_rows(const float* src, int lds_, float* dst, int ldd, int64_t rows, int cols, hipStream_t st) {
+    if (rows <= 0 || cols <= 0) return PAELLA_OK;
+    int64_t blocks = (rows * cols + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, st, src, lds_, dst, ldd, rows, cols);
+    LAUNCH_CHECK_RET();
+    return PAELLA_OK;
+}
+
+// ---------------------------------------------------------------------------
+// generic permute-copy (weight repack at load time; not on the per-step path)
+// ---------------------------------------------------------------------------
+struct PermuteArgs { int64_t oshape[5]; int64_t istride[5]; int ndim; int64_t total; };
+__global__ __launch_bounds__(256) void permute_kernel(const float* __restrict__ src, float* __restrict__ dst, PermuteArgs a) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.total; i += (int64_t)gridDim.x * 256) {
+        int64_t rem = i, off = 0;
+        for (int d = a.ndim - 1; d >= 0; --d) {
+            const int64_t q = rem / a.oshape[d];
+            off += (rem - q * a.oshape[d]) * a.istride[d];
+            rem = q;
+        }
+        dst[i] = src[off];
+    }
+}
+int launch_permute(const float* src, float* dst, const int64_t* shape, const int* perm, int ndim, hipStream_t st) {
+    if (ndim < 1 || ndim > 5) { paella_set_error("permute: ndim %d unsupported", ndim); return PAELLA_ERR_ARG; }
+    int64_t stride[5];
+    int64_t s = 1;
+    for (int d = ndim - 1; d >= 0; --d) { stride[d] = s; s *= shape[d]; }
+    PermuteArgs a;
+    a.ndim = ndim; a.total = s;
+    for (int d = 0; d < ndim; ++d) { a.oshape[d] = shape[perm[d]]; a.istride[d] = stride[perm[d]]; }
+    if (s <= 0) return PAELLA_OK;
+    int64_t blocks = (s + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(permute_kernel, dim3((unsigned)blocks), dim3(256), 0, st, src, dst, a);
+    LAUNCH_CHECK_RET();
+    return PAELLA_OK;
+}

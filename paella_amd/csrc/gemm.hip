@@ -1,0 +1,339 @@
+// fp32 "NT" GEMM for gfx950: C[M,N] = epilogue( prologue(A)[M,K] . W[N,K]^T ).
+//
+// This one kernel family carries every dense contraction of the Paella hot path
+// (reference src/modules.py: nn.Linear :49-53, 1x1 / k2s2 Conv2d :132,155, ConvTranspose2d :174,
+// MultiheadAttention in/out projections :10, clf/out_mapper :181,186; src/vqgan.py :17-21,56,66,75,81-87).
+//
+// Design (MI355X):
+//  * exact-fp32 matrix cores: v_mfma_f32_16x16x4_f32 (bitwise an fmaf chain; 157 TF peak).
+//  * operands are swapped (MFMA "A" = weight rows, "B" = activation rows) so each lane ends up with
+//    4 consecutive output channels -> 16-byte epilogue loads/stores.
+//  * 256-thread workgroups (4 waves), BK = 32, register-prefetched double-buffered LDS,
+//    one barrier per K tile; LDS tiles are [rows][32] floats with the 16-byte column slot XOR-swizzled
+//    by (row & 7): both the staging ds_write_b128 and the fragment ds_read_b128 are conflict-free.
+//  * skinny-M shapes (batch-1 sampling) fill the 256 CUs by deterministic split-K: each K slice writes an
+//    fp32 slab and a second tiny kernel sums the slabs in fixed order and applies the epilogue
+//    (no atomics -> run-to-run bit-reproducible, required for the argmax-parity contract).
+//  * XCD-aware tile order: workgroup b runs on XCD b%8; tiles that share a weight panel are made
+//    consecutive inside one XCD so the panel is fetched from HBM once and re-read from that XCD's L2.
+#include "common.h"
+#include <stdio.h>
+
+__device__ __forceinline__ float gelu_erf(float x) {
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+__device__ __forceinline__ void epilogue_store(const Epilogue& ep, float* __restrict__ C, int ldc, int N,
+                                               int m, int n, f32x4 v) {
+    if (ep.bias) v += *reinterpret_cast<const f32x4*>(ep.bias + n);
+    if (ep.act == ACT_GELU) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = gelu_erf(v[i]);
+    }
+    if (ep.alpha != 1.0f) v *= ep.alpha;
+    if (ep.residual) v += *reinterpret_cast<const f32x4*>(ep.residual + (size_t)m * ep.ldr + n);
+    if (ep.ts) {
+        const float* t = ep.ts + (size_t)(m / ep.rows_per_sample) * ep.ts_stride;
+        f32x4 a = *reinterpret_cast<const f32x4*>(t + n);
+        f32x4 b = *reinterpret_cast<const f32x4*>(t + N + n);
+        v = v * (1.0f + a) + b;
+    }
+    if (ep.store_mode == STORE_PLAIN) {
+        size_t orow = m;
+        if (ep.remap_in > 0) orow = (size_t)(m / ep.remap_in) * ep.remap_out + (m % ep.remap_in) + ep.remap_off;
+        *reinterpret_cast<f32x4*>(C + orow * ldc + n) = v;
+    } else {
+        const int hw = ep.sH * ep.sW;
+        const int b = m / hw;
+        const int rem = m - b * hw;
+        const int y = rem / ep.sW;
+        const int x = rem - y * ep.sW;
+        if (ep.store_mode == STORE_D2S) {
+            const int seg = n / ep.sC;
+            const int co = n - seg * ep.sC;
+            const int dy = seg / ep.n_seg_x;
+            const int dx = seg - dy * ep.n_seg_x;
+            const size_t orow = ((size_t)b * (2 * ep.sH) + 2 * y + dy + ep.py) * (2 * ep.sW) + 2 * x + dx + ep.px;
+            *reinterpret_cast<f32x4*>(C + orow * ldc + co) = v;
+        } else {  // STORE_PIXSHUF_NCHW: n = c*4 + dy*2 + dx -> out[b][c][2y+dy][2x+dx]
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int nn = n + i;
+                const int c = nn >> 2, dy = (nn >> 1) & 1, dx = nn & 1;
+                C[(((size_t)b * ep.sC + c) * (2 * ep.sH) + 2 * y + dy) * (2 * ep.sW) + 2 * x + dx] = v[i];
+            }
+        }
+    }
+}
+
+template <int WM, int WN, int TM, int TN, bool APRO>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g, int kslice, float* __restrict__ partial,
+                                                      int tiles_m, int tiles_n) {
+    constexpr int BM = WM * TM * 16, BN = WN * TN * 16, BK = 32;
+    constexpr int LA = (BM * 8 + 255) / 256, LB = (BN * 8 + 255) / 256;
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * BK];
+
+    // ---- XCD-aware tile id (bijective remap of blockIdx.x) ----
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_m = bid % tiles_m;  // m fastest: neighbours share the weight panel
+    const int tile_n = bid / tiles_m;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int kbeg = blockIdx.y * kslice;
+    const int kend = min(g.K, kbeg + kslice);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int ldrow = tid >> 3, ldc4 = tid & 7;
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    f32x4 ra[LA], rb[LB];
+
+    auto load_tile = [&](int k0) {
+        const int k = k0 + ldc4 * 4;
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+            const int row = ldrow + i * 32;
+            const int gm = m0 + row;
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (row < BM && gm < g.M && k < kend) {
+                v = *reinterpret_cast<const f32x4*>(g.A + (size_t)gm * g.lda + k);
+                if (APRO) {
+                    const int b = gm / g.a_rows_per_sample;
+                    const f32x4 s = *reinterpret_cast<const f32x4*>(g.a_scale + (size_t)b * g.K + k);
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(g.a_shift + k);
+                    v = v * s + t;
+                }
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < LB; ++i) {
+            const int row = ldrow + i * 32;
+            const int gn = n0 + row;
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (row < BN && gn < g.N && k < kend)
+                v = *reinterpret_cast<const f32x4*>(g.W + (size_t)gn * g.ldw + k);
+            rb[i] = v;
+        }
+    };
+    auto store_tile = [&](int buf) {
+        float* As = smem + buf * (BM + BN) * BK;
+        float* Bs = As + BM * BK;
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+            const int row = ldrow + i * 32;
+            if (row < BM) *reinterpret_cast<f32x4*>(As + row * BK + ((ldc4 ^ (row & 7)) << 2)) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < LB; ++i) {
+            const int row = ldrow + i * 32;
+            if (row < BN) *reinterpret_cast<f32x4*>(Bs + row * BK + ((ldc4 ^ (row & 7)) << 2)) = rb[i];
+        }
+    };
+
+    const int ntiles = (kend - kbeg + BK - 1) / BK;
+    if (ntiles > 0) {
+        load_tile(kbeg);
+        store_tile(0);
+    }
+    __syncthreads();
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < ntiles) load_tile(kbeg + (t + 1) * BK);
+        const float* As = smem + buf * (BM + BN) * BK;
+        const float* Bs = As + BM * BK;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            f32x4 af[TM], bf[TN];
+            const int c4 = kk * 4 + kq;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = (wm * TM + i) * 16 + r16;
+                af[i] = *reinterpret_cast<const f32x4*>(As + row * BK + ((c4 ^ (row & 7)) << 2));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int row = (wn * TN + j) * 16 + r16;
+                bf[j] = *reinterpret_cast<const f32x4*>(Bs + row * BK + ((c4 ^ (row & 7)) << 2));
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][e], af[i][e], acc[i][j], 0, 0, 0);
+        }
+        if (t + 1 < ntiles) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds out[m = ..+r16][n = ..+kq*4 .. +3] ----
+    const bool split = (partial != nullptr);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + (wm * TM + i) * 16 + r16;
+        if (m >= g.M) continue;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + (wn * TN + j) * 16 + kq * 4;
+            if (n >= g.N) continue;
+            if (split) {
+                *reinterpret_cast<f32x4*>(partial + ((size_t)blockIdx.y * g.M + m) * g.N + n) = acc[i][j];
+            } else {
+                epilogue_store(g.ep, g.C, g.ldc, g.N, m, n, acc[i][j]);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int S, int M, int N,
+                                                            float* __restrict__ C, int ldc, Epilogue ep) {
+    const int n4 = N >> 2;
+    const size_t total = (size_t)M * n4;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int m = (int)(idx / n4);
+        const int n = (int)(idx - (size_t)m * n4) << 2;
+        const float* p = partial + (size_t)m * N + n;
+        f32x4 v = *reinterpret_cast<const f32x4*>(p);
+        for (int s = 1; s < S; ++s) v += *reinterpret_cast<const f32x4*>(p + (size_t)s * M * N);
+        epilogue_store(ep, C, ldc, N, m, n, v);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+struct TileCfg { int wm, wn, tm, tn; };
+static const TileCfg kCfgs[] = {
+    {2, 2, 4, 4},  // 0: 128x128
+    {2, 2, 4, 2},  // 1: 128x64
+    {2, 2, 2, 2},  // 2: 64x64
+    {2, 2, 2, 1},  // 3: 64x32
+    {2, 2, 1, 2},  // 4: 32x64
+    {2, 2, 1, 1},  // 5: 32x32
+    {1, 4, 1, 1},  // 6: 16x64
+    {1, 4, 1, 2},  // 7: 16x128
+    {1, 4, 2, 2},  // 8: 32x128
+};
+static const int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
+
+template <int WM, int WN, int TM, int TN>
+static void launch_one(const GemmArgs& g, int kslice, int S, float* partial, hipStream_t st) {
+    constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+    dim3 grid(tiles_m * tiles_n, S);
+    if (g.a_scale)
+        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, true>), grid, dim3(256), 0, st, g, kslice, partial, tiles_m, tiles_n);
+    else
+        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, false>), grid, dim3(256), 0, st, g, kslice, partial, tiles_m, tiles_n);
+}
+
+size_t gemm_splitk_ws_bytes(int M, int N, int K) {
+    (void)K;
+    return (size_t)16 * M * N * sizeof(float);  // up to 16 slabs
+}
+
+// Cost model (cycles, arbitrary but consistent units) used to pick tile + split for a shape.
+static void choose_config(int M, int N, int K, size_t ws_bytes, int* cfg_out, int* split_out) {
+    double best = 1e30;
+    int bc = 2, bs = 1;
+    for (int c = 0; c < kNumCfgs; ++c) {
+        const int BM = kCfgs[c].wm * kCfgs[c].tm * 16, BN = kCfgs[c].wn * kCfgs[c].tn * 16;
+        const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
+        const long tiles = (long)tm * tn;
+        const int lds = 2 * (BM + BN) * 32 * 4;
+        int occ = 160 * 1024 / lds;
+        if (occ > 4) occ = 4;
+        if (occ < 1) occ = 1;
+        for (int S = 1; S <= 16; S *= 2) {
+            int ks = ((K + S - 1) / S + 31) / 32 * 32;
+            if (S > 1 && (ks < 128 || (size_t)S * M * N * 4 > ws_bytes)) break;
+            const int Seff = (K + ks - 1) / ks;
+            const long wgs = tiles * Seff;
+            // per-workgroup time if it had a CU alone
+            const double mfma = (double)BM * BN * ks / 128.0;            // 256 flop/clk/CU
+            const double mem = (double)(BM + BN) * ks * 4.0 / 24.0;      // ~24 B/clk/CU sustained from L2/HBM
+            const double one = (mfma > mem ? mfma : mem) + 1500.0;       // + prologue/epilogue latency
+            // CU-rounds: `occ` co-resident workgroups share the CU's pipes
+            const long slots = 256L * occ;
+            const long rounds = (wgs + slots - 1) / slots;
+            const long last = wgs - (rounds - 1) * slots;                // workgroups in the last round
+            const double per_cu_last = (double)((last + 255) / 256);
+            double t = (rounds - 1) * one * occ + per_cu_last * one;
+            if (Seff > 1) t += 4000.0 + (double)Seff * M * N * 4.0 / 1500.0;  // reduce launch + slab traffic
+            if (t < best) { best = t; bc = c; bs = Seff; }
+        }
+    }
+    *cfg_out = bc;
+    *split_out = bs;
+}
+
+int launch_gemm_cfg(const GemmArgs& g, int cfg, int splitk, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (g.M <= 0 || g.N <= 0) return PAELLA_OK;
+    if ((g.K & 3) || (g.N & 3) || (g.lda & 3) || (g.ldw & 3) || (g.ldc & 3 && g.ep.store_mode != STORE_PIXSHUF_NCHW)) {
+        paella_set_error("gemm: K, N, lda, ldw, ldc must be multiples of 4 (M=%d N=%d K=%d lda=%d ldw=%d ldc=%d)",
+                         g.M, g.N, g.K, g.lda, g.ldw, g.ldc);
+        return PAELLA_ERR_ARG;
+    }
+    if (g.ep.store_mode == STORE_D2S && (g.ep.sC & 3)) {
+        paella_set_error("gemm: depth-to-space store needs channels %% 4 == 0");
+        return PAELLA_ERR_ARG;
+    }
+    int S = splitk;
+    if (cfg < 0) choose_config(g.M, g.N, g.K, ws ? ws_bytes : 0, &cfg, &S);
+    if (cfg >= kNumCfgs) { paella_set_error("gemm: bad tile config %d", cfg); return PAELLA_ERR_ARG; }
+    if (S < 1) S = 1;
+    int kslice = ((g.K + S - 1) / S + 31) / 32 * 32;
+    S = (g.K + kslice - 1) / kslice;
+    if (S < 1) S = 1;
+    float* partial = nullptr;
+    if (S > 1) {
+        if ((size_t)S * g.M * g.N * sizeof(float) > ws_bytes || !ws) {
+            paella_set_error("gemm: split-K workspace too small");
+            return PAELLA_ERR_WORKSPACE;
+        }
+        partial = reinterpret_cast<float*>(ws);
+    }
+    switch (cfg) {
+        case 0: launch_one<2, 2, 4, 4>(g, kslice, S, partial, st); break;
+        case 1: launch_one<2, 2, 4, 2>(g, kslice, S, partial, st); break;
+        case 2: launch_one<2, 2, 2, 2>(g, kslice, S, partial, st); break;
+        case 3: launch_one<2, 2, 2, 1>(g, kslice, S, partial, st); break;
+        case 4: launch_one<2, 2, 1, 2>(g, kslice, S, partial, st); break;
+        case 5: launch_one<2, 2, 1, 1>(g, kslice, S, partial, st); break;
+        case 6: launch_one<1, 4, 1, 1>(g, kslice, S, partial, st); break;
+        case 7: launch_one<1, 4, 1, 2>(g, kslice, S, partial, st); break;
+        case 8: launch_one<1, 4, 2, 2>(g, kslice, S, partial, st); break;
+    }
+    LAUNCH_CHECK_RET();
+    if (S > 1) {
+        const size_t total = (size_t)g.M * (g.N >> 2);
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, partial, S, g.M, g.N, g.C, g.ldc, g.ep);
+        LAUNCH_CHECK_RET();
+    }
+    return PAELLA_OK;
+}
+
+int launch_gemm(const GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t st) {
+    return launch_gemm_cfg(g, -1, 1, ws, ws_bytes, st);
+}

@@ -1,0 +1,738 @@
+// Denoising-UNet execution plan and C ABI (include/paella_hip.h) for gfx950.
+//
+// The whole forward (reference src/modules.py:263-275 Paella.forward, :234-261 _down_encode/_up_decode) is
+// enqueued by ONE call from the host: the block list is walked natively, every op is a HIP kernel from
+// gemm.hip / elementwise.hip / attention.hip, activations stay NHWC in a caller-owned workspace arena, and
+// nothing synchronises the host.  Weights are repacked once at load (paella_unet_load_tensor).
+#include "internal.h"
+#include "../../include/paella_hip.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+// ---------------------------------------------------------------------------
+// error string
+// ---------------------------------------------------------------------------
+static thread_local char g_err[2048] = "";
+void paella_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* paella_last_error(void) { return g_err; }
+extern "C" int paella_abi_version(void) { return PAELLA_ABI_VERSION; }
+
+// ---------------------------------------------------------------------------
+// library-owned device tensors
+// ---------------------------------------------------------------------------
+int devbuf_alloc(DevBuf& b, size_t n) {
+    if (b.p && b.n == n) return PAELLA_OK;
+    if (b.p) { (void)hipFree(b.p); b.p = nullptr; }
+    b.n = n;
+    HIP_CHECK_RET(hipMalloc((void**)&b.p, (n ? n : 1) * sizeof(float)));
+    return PAELLA_OK;
+}
+
+// ---------------------------------------------------------------------------
+// plan
+// ---------------------------------------------------------------------------
+enum BlockType { BT_RES, BT_TS, BT_ATTN, BT_FF, BT_DOWN, BT_UP };
+
+struct TensorSpec {
+    Repack kind;
+    std::vector<int64_t> shape;  // expected reference shape
+    int aux = 0;                 // RP_TS_*: offset into the concatenated timestep mapper
+};
+
+struct Block {
+    BlockType type;
+    int level = 0;
+    int c = 0;
+    std::string prefix;
+    bool has_skip = false;
+    int ts_offset = -1;        // BT_TS: offset of [a|b] in the ts vector
+    bool ts_standalone = true; // BT_TS: false when fused into the previous block's GEMM epilogue
+    int fused_ts = -1;         // BT_RES/BT_FF: ts offset fused into GEMM2, or -1
+    int attn_index = -1;
+    int c_from = 0, c_to = 0;  // samplers
+};
+
+struct paella_unet {
+    paella_unet_config cfg;
+    std::vector<Block> down, up;  // execution order, samplers included
+    std::map<std::string, TensorSpec> specs;
+    std::map<std::string, DevBuf> t;
+    DevBuf ts_w, ts_b, freqs;
+    int ts_total = 0;
+    int n_attn = 0;
+    std::vector<int> attn_c;      // channel width per attention block (execution order)
+    bool finalized = false;
+    bool freqs_set = false;
+    int c_max = 0;
+};
+
+static const float* T(const paella_unet* m, const std::string& k) {
+    auto it = m->t.find(k);
+    return it == m->t.end() ? nullptr : it->second.p;
+}
+
+static void add_spec(paella_unet* m, const std::string& key, Repack kind, std::vector<int64_t> shape, int aux = 0) {
+    TensorSpec s;
+    s.kind = kind; s.shape = std::move(shape); s.aux = aux;
+    m->specs[key] = s;
+}
+
+static int build_plan(paella_unet* m) {
+    const paella_unet_config& c = m->cfg;
+    if (c.n_levels < 1 || c.n_levels > PAELLA_MAX_LEVELS) { paella_set_error("n_levels out of range"); return PAELLA_ERR_ARG; }
+    if (c.kernel_size != 3) { paella_set_error("kernel_size %d unsupported (3 only)", c.kernel_size); return PAELLA_ERR_ARG; }
+    if (c.patch_size != 1 && c.patch_size != 2) { paella_set_error("patch_size %d unsupported (1 or 2)", c.patch_size); return PAELLA_ERR_ARG; }
+    if ((c.c_in & 3) || (c.c_out & 3) || (c.num_labels & 3) || (c.c_cond & 3) || (c.clip_embd & 3) || (c.byt5_embd & 3)) {
+        paella_set_error("c_in, c_out, num_labels, c_cond, clip_embd, byt5_embd must be multiples of 4");
+        return PAELLA_ERR_ARG;
+    }
+    const int p2 = c.patch_size * c.patch_size;
+    const int64_t cr = c.c_r, cc = c.c_cond;
+    add_spec(m, "byt5_mapper.weight", RP_COPY, {cc, c.byt5_embd});
+    add_spec(m, "byt5_mapper.bias", RP_COPY, {cc});
+    add_spec(m, "clip_mapper.weight", RP_COPY, {cc * c.clip_seq_len, c.clip_embd});
+    add_spec(m, "clip_mapper.bias", RP_COPY, {cc * c.clip_seq_len});
+    add_spec(m, "clip_image_mapper.weight", RP_COPY, {cc * c.clip_seq_len, c.clip_embd});
+    add_spec(m, "clip_image_mapper.bias", RP_COPY, {cc * c.clip_seq_len});
+    add_spec(m, "in_mapper.0.weight", RP_COPY, {c.num_labels, c.c_in});
+    add_spec(m, "embedding.1.weight", RP_COPY, {c.c_hidden[0], (int64_t)c.c_in * p2, 1, 1});
+    add_spec(m, "embedding.1.bias", RP_COPY, {c.c_hidden[0]});
+    add_spec(m, "clf.1.weight", RP_CLF_W, {(int64_t)c.c_out * p2, c.c_hidden[0], 1, 1});
+    add_spec(m, "clf.1.bias", RP_CLF_B, {(int64_t)c.c_out * p2});
+    add_spec(m, "out_mapper.1.weight", RP_COPY, {c.num_labels, c.c_out, 1, 1});
+
+    int ts_total = 0, n_attn = 0;
+    auto add_block = [&](std::vector<Block>& seq, char type, int level, const std::string& prefix, bool skip) -> int {
+        Block b;
+        b.level = level; b.c = c.c_hidden[level]; b.prefix = prefix;
+        const int64_t ch = b.c;
+        if (ch & 7) { paella_set_error("c_hidden[%d]=%d must be a multiple of 8", level, b.c); return PAELLA_ERR_ARG; }
+        switch (type) {
+            case 'C':
+                b.type = BT_RES; b.has_skip = skip;
+                add_spec(m, prefix + ".depthwise.weight", RP_DW, {ch, skip ? 2 : 1, 3, 3});
+                add_spec(m, prefix + ".depthwise.bias", RP_COPY, {ch});
+                /* fallthrough */
+            case 'F':
+                if (type == 'F') b.type = BT_FF;
+                add_spec(m, prefix + ".channelwise.0.weight", RP_COPY, {4 * ch, ch});
+                add_spec(m, prefix + ".channelwise.0.bias", RP_COPY, {4 * ch});
+                add_spec(m, prefix + ".channelwise.2.gamma", RP_COPY, {1, 1, 1, 4 * ch});
+                add_spec(m, prefix + ".channelwise.2.beta", RP_COPY, {1, 1, 1, 4 * ch});
+                add_spec(m, prefix + ".channelwise.4.weight", RP_COPY, {ch, 4 * ch});
+                add_spec(m, prefix + ".channelwise.4.bias", RP_COPY, {ch});
+                break;
+            case 'T':
+                b.type = BT_TS; b.ts_offset = ts_total;
+                add_spec(m, prefix + ".mapper.weight", RP_TS_W, {2 * ch, cr}, ts_total);
+                add_spec(m, prefix + ".mapper.bias", RP_TS_B, {2 * ch}, ts_total);
+                ts_total += 2 * b.c;
+                if (!seq.empty() && (seq.back().type == BT_RES || seq.back().type == BT_FF) && seq.back().level == level &&
+                    seq.back().fused_ts < 0) {
+                    seq.back().fused_ts = b.ts_offset;
+                    b.ts_standalone = false;
+                }
+                break;
+            case 'A': {
+                b.type = BT_ATTN; b.attn_index = n_attn++;
+                m->attn_c.push_back(b.c);
+                const int nh = c.nhead[level];
+                if (nh <= 0 || b.c % nh || (b.c / nh) % 16 || b.c / nh > 128) {
+                    paella_set_error("level %d: c=%d nhead=%d -> head_dim must be a multiple of 16 and <= 128", level, b.c, nh);
+                    return PAELLA_ERR_ARG;
+                }
+                add_spec(m, prefix + ".attention.attn.in_proj_weight", RP_COPY, {3 * ch, ch});
+                add_spec(m, prefix + ".attention.attn.in_proj_bias", RP_COPY, {3 * ch});
+                add_spec(m, prefix + ".attention.attn.out_proj.weight", RP_COPY, {ch, ch});
+                add_spec(m, prefix + ".attention.attn.out_proj.bias", RP_COPY, {ch});
+                add_spec(m, prefix + ".kv_mapper.1.weight", RP_COPY, {ch, cc});
+                add_spec(m, prefix + ".kv_mapper.1.bias", RP_COPY, {ch});
+                break;
+            }
+            default:
+                paella_set_error("Block type %c not supported", type);
+                return PAELLA_ERR_ARG;
+        }
+        seq.push_back(b);
+        return PAELLA_OK;
+    };
+
+    char buf[128];
+    // DOWN (reference src/modules.py:148-160)
+    for (int i = 0; i < c.n_levels; ++i) {
+        int j = 0;
+        if (i > 0) {
+            Block b;
+            b.type = BT_DOWN; b.level = i; b.c = c.c_hidden[i]; b.c_from = c.c_hidden[i - 1]; b.c_to = c.c_hidden[i];
+            snprintf(buf, sizeof buf, "down_blocks.%d.0", i);
+            b.prefix = buf;
+            add_spec(m, b.prefix + ".1.weight", RP_CONV_K2, {b.c_to, b.c_from, 2, 2});
+            add_spec(m, b.prefix + ".1.bias", RP_COPY, {b.c_to});
+            m->down.push_back(b);
+            j = 1;
+        }
+        for (int r = 0; r < c.blocks[i]; ++r)
+            for (const char* t = c.level_config[i]; *t; ++t) {
+                snprintf(buf, sizeof buf, "down_blocks.%d.%d", i, j++);
+                RET_IF(add_block(m->down, *t, i, buf, false));
+            }
+    }
+    // UP (reference src/modules.py:163-176)
+    for (int u = 0; u < c.n_levels; ++u) {
+        const int i = c.n_levels - 1 - u;
+        int j = 0;
+        for (int r = 0; r < c.blocks[i]; ++r) {
+            int k = 0;
+            for (const char* t = c.level_config[i]; *t; ++t, ++k) {
+                snprintf(buf, sizeof buf, "up_blocks.%d.%d", u, j++);
+                const bool skip = (i < c.n_levels - 1) && r == 0 && k == 0 && *t == 'C';
+                RET_IF(add_block(m->up, *t, i, buf, skip));
+            }
+        }
+        if (i > 0) {
+            Block b;
+            b.type = BT_UP; b.level = i; b.c = c.c_hidden[i]; b.c_from = c.c_hidden[i]; b.c_to = c.c_hidden[i - 1];
+            snprintf(buf, sizeof buf, "up_blocks.%d.%d", u, j);
+            b.prefix = buf;
+            add_spec(m, b.prefix + ".1.weight", RP_CONVT_K2, {b.c_from, b.c_to, 2, 2});
+            add_spec(m, b.prefix + ".1.bias", RP_TILE4, {b.c_to});
+            m->up.push_back(b);
+        }
+    }
+    m->ts_total = ts_total;
+    m->n_attn = n_attn;
+    m->c_max = 0;
+    for (int i = 0; i < c.n_levels; ++i) m->c_max = c.c_hidden[i] > m->c_max ? c.c_hidden[i] : m->c_max;
+    return PAELLA_OK;
+}
+
+extern "C" int paella_unet_create(const paella_unet_config* cfg, paella_unet** out) {
+    if (!cfg || !out) { paella_set_error("null argument"); return PAELLA_ERR_ARG; }
+    paella_unet* m = new paella_unet();
+    m->cfg = *cfg;
+    for (int i = 0; i < PAELLA_MAX_LEVELS; ++i) m->cfg.level_config[i][PAELLA_MAX_BLOCK_TYPES - 1] = 0;
+    int rc = build_plan(m);
+    if (rc != PAELLA_OK) { delete m; return rc; }
+    if (m->ts_total > 0) {
+        rc = devbuf_alloc(m->ts_w, (size_t)m->ts_total * cfg->c_r);
+        if (rc == PAELLA_OK) rc = devbuf_alloc(m->ts_b, (size_t)m->ts_total);
+        if (rc != PAELLA_OK) { delete m; return rc; }
+    }
+    *out = m;
+    return PAELLA_OK;
+}
+
+extern "C" void paella_unet_destroy(paella_unet* m) {
+    if (!m) return;
+    for (auto& kv : m->t) if (kv.second.p) (void)hipFree(kv.second.p);
+    if (m->ts_w.p) (void)hipFree(m->ts_w.p);
+    if (m->ts_b.p) (void)hipFree(m->ts_b.p);
+    if (m->freqs.p) (void)hipFree(m->freqs.p);
+    delete m;
+}
+
+// shared by the UNet and VQGAN loaders
+int repack_into(Repack kind, const float* src, const std::vector<int64_t>& shape, DevBuf& dst, hipStream_t st) {
+    int64_t numel = 1;
+    for (int64_t d : shape) numel *= d;
+    switch (kind) {
+        case RP_COPY:
+            RET_IF(devbuf_alloc(dst, numel));
+            HIP_CHECK_RET(hipMemcpyAsync(dst.p, src, numel * sizeof(float), hipMemcpyDeviceToDevice, st));
+            break;
+        case RP_DW: {  // [C, J, 3, 3] -> [J, 3, 3, C]
+            RET_IF(devbuf_alloc(dst, numel));
+            const int perm[4] = {1, 2, 3, 0};
+            RET_IF(launch_permute(src, dst.p, shape.data(), perm, 4, st));
+            break;
+        }
+        case RP_CONV_K2: {  // [co, ci, kh, kw] -> [co, kh, kw, ci]
+            RET_IF(devbuf_alloc(dst, numel));
+            const int perm[4] = {0, 2, 3, 1};
+            RET_IF(launch_permute(src, dst.p, shape.data(), perm, 4, st));
+            break;
+        }
+        case RP_CONVT_K2: {  // [ci, co, kh, kw] -> [kh, kw, co, ci]
+            RET_IF(devbuf_alloc(dst, numel));
+            const int perm[4] = {2, 3, 1, 0};
+            RET_IF(launch_permute(src, dst.p, shape.data(), perm, 4, st));
+            break;
+        }
+        case RP_TILE4:  // [c] -> [4][c]
+            RET_IF(devbuf_alloc(dst, numel * 4));
+            for (int r = 0; r < 4; ++r)
+                HIP_CHECK_RET(hipMemcpyAsync(dst.p + r * numel, src, numel * sizeof(float), hipMemcpyDeviceToDevice, st));
+            break;
+        default:
+            paella_set_error("internal: unexpected repack kind");
+            return PAELLA_ERR_STATE;
+    }
+    dst.loaded = true;
+    return PAELLA_OK;
+}
+
+extern "C" int paella_unet_load_tensor(paella_unet* m, const char* key, const float* dev_src, const int64_t* shape, int ndim,
+                                       void* stream) {
+    if (!m || !key || !dev_src) { paella_set_error("null argument"); return PAELLA_ERR_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    auto it = m->specs.find(key);
+    if (it == m->specs.end()) { paella_set_error("unexpected state-dict key '%s'", key); return PAELLA_ERR_ARG; }
+    const TensorSpec& sp = it->second;
+    if ((int)sp.shape.size() != ndim) { paella_set_error("%s: expected %d dims, got %d", key, (int)sp.shape.size(), ndim); return PAELLA_ERR_ARG; }
+    int64_t numel = 1;
+    for (int d = 0; d < ndim; ++d) {
+        if (shape[d] != sp.shape[d]) { paella_set_error("%s: dim %d is %lld, expected %lld", key, d, (long long)shape[d], (long long)sp.shape[d]); return PAELLA_ERR_ARG; }
+        numel *= shape[d];
+    }
+    const int p2 = m->cfg.patch_size * m->cfg.patch_size;
+    DevBuf& dst = m->t[key];
+    switch (sp.kind) {
+        case RP_TS_W:
+            HIP_CHECK_RET(hipMemcpyAsync(m->ts_w.p + (size_t)sp.aux * m->cfg.c_r, dev_src, numel * sizeof(float), hipMemcpyDeviceToDevice, st));
+            dst.loaded = true;
+            break;
+        case RP_TS_B:
+            HIP_CHECK_RET(hipMemcpyAsync(m->ts_b.p + sp.aux, dev_src, numel * sizeof(float), hipMemcpyDeviceToDevice, st));
+            dst.loaded = true;
+            break;
+        case RP_CLF_W: {  // [c_out*p2, c0] rows (c, s) -> (s, c)
+            RET_IF(devbuf_alloc(dst, numel));
+            const int64_t sh[3] = {m->cfg.c_out, p2, m->cfg.c_hidden[0]};
+            const int perm[3] = {1, 0, 2};
+            RET_IF(launch_permute(dev_src, dst.p, sh, perm, 3, st));
+            dst.loaded = true;
+            break;
+        }
+        case RP_CLF_B: {
+            RET_IF(devbuf_alloc(dst, numel));
+            const int64_t sh[2] = {m->cfg.c_out, p2};
+            const int perm[2] = {1, 0};
+            RET_IF(launch_permute(dev_src, dst.p, sh, perm, 2, st));
+            dst.loaded = true;
+            break;
+        }
+        default:
+            RET_IF(repack_into(sp.kind, dev_src, sp.shape, dst, st));
+    }
+    return PAELLA_OK;
+}
+
+extern "C" int paella_unet_set_timestep_freqs(paella_unet* m, const float* host_freqs, int n) {
+    if (!m || !host_freqs) { paella_set_error("null argument"); return PAELLA_ERR_ARG; }
+    if (n != m->cfg.c_r / 2) { paella_set_error("expected %d frequencies, got %d", m->cfg.c_r / 2, n); return PAELLA_ERR_ARG; }
+    RET_IF(devbuf_alloc(m->freqs, n));
+    HIP_CHECK_RET(hipMemcpy(m->freqs.p, host_freqs, n * sizeof(float), hipMemcpyHostToDevice));
+    m->freqs_set = true;
+    return PAELLA_OK;
+}
+
+extern "C" int paella_unet_finalize(paella_unet* m, void* stream) {
+    (void)stream;
+    if (!m) { paella_set_error("null argument"); return PAELLA_ERR_ARG; }
+    for (auto& kv : m->specs) {
+        auto it = m->t.find(kv.first);
+        if (it == m->t.end() || !it->second.loaded) { paella_set_error("tensor '%s' was never loaded", kv.first.c_str()); return PAELLA_ERR_STATE; }
+    }
+    if (!m->freqs_set) {
+        const int half = m->cfg.c_r / 2;
+        std::vector<float> f(half > 0 ? half : 1);
+        const float e = logf(10000.0f) / (float)(half - 1);
+        for (int k = 0; k < half; ++k) f[k] = expf((float)k * -e);
+        RET_IF(paella_unet_set_timestep_freqs(m, f.data(), half));
+    }
+    m->finalized = true;
+    return PAELLA_OK;
+}
+
+// ---------------------------------------------------------------------------
+// conditioning cache layout: per attention block i (execution order) a [B*S, 2*c_i] matrix (K | V)
+// ---------------------------------------------------------------------------
+static size_t cond_offset_floats(const paella_unet* m, int i, int B, int S) {
+    size_t off = 0;
+    for (int k = 0; k < i; ++k) off += (((size_t)B * S * 2 * m->attn_c[k]) + 63) & ~(size_t)63;
+    return off;
+}
+
+extern "C" size_t paella_unet_cond_bytes(const paella_unet* m, int B, int S) {
+    if (!m) return 0;
+    const size_t n = cond_offset_floats(m, m->n_attn, B, S);
+    return (n ? n : 64) * sizeof(float);
+}
+
+struct FwdBuffers {
+    float* xl[PAELLA_MAX_LEVELS];
+    float* xu[PAELLA_MAX_LEVELS];
+    float *h, *g, *grn_scale, *grn_gx, *ts, *remb, *splitk;
+    // cond_prepare
+    float *c_embed, *c_silu, *kvm;
+};
+
+static int64_t level_rows(const paella_unet* m, int B, int H, int W, int l) {
+    const int p = m->cfg.patch_size;
+    return (int64_t)B * ((H / p) >> l) * ((W / p) >> l);
+}
+
+static void carve_forward(const paella_unet* m, Arena& a, int B, int H, int W, int S, FwdBuffers& f) {
+    const paella_unet_config& c = m->cfg;
+    const int p2 = c.patch_size * c.patch_size;
+    size_t hmax = (size_t)B * H * W * c.c_out;
+    size_t gmax = (size_t)B * H * W * c.c_out;
+    const size_t emb = (size_t)level_rows(m, B, H, W, 0) * c.c_in * p2;
+    if (emb > hmax) hmax = emb;
+    for (int l = 0; l < c.n_levels; ++l) {
+        const size_t n = (size_t)level_rows(m, B, H, W, l) * c.c_hidden[l];
+        f.xl[l] = a.take(n);
+        f.xu[l] = (l < c.n_levels - 1) ? a.take(n) : nullptr;
+        if (n > hmax) hmax = n;
+        if (4 * n > gmax) gmax = 4 * n;
+    }
+    f.h = a.take(hmax);
+    f.g = a.take(gmax);
+    f.grn_scale = a.take((size_t)B * 4 * m->c_max);
+    f.grn_gx = a.take((size_t)B * 4 * m->c_max);
+    f.ts = a.take((size_t)B * (m->ts_total > 0 ? m->ts_total : 1));
+    f.remb = a.take((size_t)B * c.c_r);
+    f.splitk = a.take(kSplitKBudget / sizeof(float));
+    (void)S;
+}
+
+static void carve_cond(const paella_unet* m, Arena& a, int B, int S, FwdBuffers& f) {
+    f.c_embed = a.take((size_t)B * S * m->cfg.c_cond);
+    f.c_silu = a.take((size_t)B * S * m->cfg.c_cond);
+    f.kvm = a.take((size_t)B * S * m->c_max);
+    f.splitk = a.take(kSplitKBudget / sizeof(float));
+}
+
+extern "C" size_t paella_unet_workspace_bytes(const paella_unet* m, int B, int H, int W, int S) {
+    if (!m) return 0;
+    FwdBuffers f;
+    Arena a(nullptr, 0);
+    carve_forward(m, a, B, H, W, S, f);
+    Arena c(nullptr, 0);
+    carve_cond(m, c, B, S, f);
+    return (a.off > c.off ? a.off : c.off) + 256;
+}
+
+// gen_c_embeddings (reference src/modules.py:223-232; list-valued clip_image utils/modules.py:229-235):
+// seq = cat([byt5_mapper(byt5), clip_mapper(clip).view(B,-1,c_cond), clip_image_mapper(ci).view(...)...], dim=1); seq_norm
+static int compute_c_embed(const paella_unet* m, const float* byt5, int S_byt5, const float* clip, const float* const* clip_image,
+                           int n_clip_image, int B, int S, float* c_embed, float* splitk, hipStream_t st) {
+    const paella_unet_config& c = m->cfg;
+    const size_t skb = kSplitKBudget;
+    const int cc = c.c_cond;
+    if (S_byt5 > 0) {
+        GemmArgs g = gemm_args(byt5, c.byt5_embd, T(m, "byt5_mapper.weight"), c.byt5_embd, c_embed, cc, B * S_byt5, cc, c.byt5_embd);
+        g.ep.bias = T(m, "byt5_mapper.bias");
+        g.ep.remap_in = S_byt5; g.ep.remap_out = S; g.ep.remap_off = 0;
+        RET_IF(launch_gemm(g, splitk, skb, st));
+    }
+    int row_off = S_byt5;
+    if (clip) {
+        GemmArgs g = gemm_args(clip, c.clip_embd, T(m, "clip_mapper.weight"), c.clip_embd, c_embed + (size_t)row_off * cc, S * cc, B,
+                               cc * c.clip_seq_len, c.clip_embd);
+        g.ep.bias = T(m, "clip_mapper.bias");
+        RET_IF(launch_gemm(g, splitk, skb, st));
+        row_off += c.clip_seq_len;
+    }
+    for (int i = 0; i < n_clip_image; ++i) {
+        if (!clip_image || !clip_image[i]) { paella_set_error("clip_image[%d] is null", i); return PAELLA_ERR_ARG; }
+        GemmArgs g = gemm_args(clip_image[i], c.clip_embd, T(m, "clip_image_mapper.weight"), c.clip_embd,
+                               c_embed + (size_t)row_off * cc, S * cc, B, cc * c.clip_seq_len, c.clip_embd);
+        g.ep.bias = T(m, "clip_image_mapper.bias");
+        RET_IF(launch_gemm(g, splitk, skb, st));
+        row_off += c.clip_seq_len;
+    }
+    RET_IF(launch_layernorm(c_embed, c_embed, (int64_t)B * S, cc, 1e-6f, 1.f, 0.f, 0, 0, 0, st));
+    return PAELLA_OK;
+}
+
+extern "C" int paella_unet_c_embeddings(paella_unet* m, const float* byt5, int S_byt5, const float* clip,
+                                        const float* const* clip_image, int n_clip_image, int B, float* c_embed_out, void* ws,
+                                        size_t ws_bytes, void* stream) {
+    if (!m || !m->finalized) { paella_set_error("model not finalized"); return PAELLA_ERR_STATE; }
+    const int S = S_byt5 + (clip ? m->cfg.clip_seq_len : 0) + n_clip_image * m->cfg.clip_seq_len;
+    if (B <= 0 || S <= 0 || !c_embed_out) { paella_set_error("bad conditioning shape"); return PAELLA_ERR_ARG; }
+    if (ws_bytes < kSplitKBudget || !ws) { paella_set_error("workspace too small"); return PAELLA_ERR_WORKSPACE; }
+    return compute_c_embed(m, byt5, S_byt5, clip, clip_image, n_clip_image, B, S, c_embed_out, (float*)ws, (hipStream_t)stream);
+}
+
+extern "C" int paella_unet_r_embedding(paella_unet* m, const float* r, int B, float max_positions, float* r_embed_out, void* stream) {
+    if (!m || !m->finalized) { paella_set_error("model not finalized"); return PAELLA_ERR_STATE; }
+    if (!r || !r_embed_out) { paella_set_error("null argument"); return PAELLA_ERR_ARG; }
+    return launch_timestep(r, m->freqs.p, m->ts_w.p, m->ts_b.p, nullptr, B, m->cfg.c_r, 0, max_positions, r_embed_out, (hipStream_t)stream);
+}
+
+extern "C" int paella_unet_cond_prepare(paella_unet* m, const float* byt5, int S_byt5, const float* clip,
+                                        const float* const* clip_image, int n_clip_image, int B, void* cond_out,
+                                        size_t cond_bytes, void* ws, size_t ws_bytes, void* stream) {
+    if (!m || !m->finalized) { paella_set_error("model not finalized"); return PAELLA_ERR_STATE; }
+    hipStream_t st = (hipStream_t)stream;
+    const paella_unet_config& c = m->cfg;
+    const int S = S_byt5 + (clip ? c.clip_seq_len : 0) + n_clip_image * c.clip_seq_len;
+    if (B <= 0 || S_byt5 < 0 || n_clip_image < 0) { paella_set_error("bad conditioning shape"); return PAELLA_ERR_ARG; }
+    if (m->n_attn == 0) return PAELLA_OK;
+    if (S <= 0 ) { paella_set_error("conditioning sequence is empty"); return PAELLA_ERR_ARG; }
+    if (S_byt5 > 0 && !byt5) { paella_set_error("byt5 is null"); return PAELLA_ERR_ARG; }
+    if (cond_bytes < paella_unet_cond_bytes(m, B, S) || !cond_out) { paella_set_error("cond buffer too small"); return PAELLA_ERR_WORKSPACE; }
+    FwdBuffers f;
+    Arena a(ws, ws_bytes);
+    carve_cond(m, a, B, S, f);
+    if (!a.ok || !ws) { paella_set_error("workspace too small (%zu needed)", a.off); return PAELLA_ERR_WORKSPACE; }
+    const size_t skb = kSplitKBudget;
+
+    const int cc = c.c_cond;
+    RET_IF(compute_c_embed(m, byt5, S_byt5, clip, clip_image, n_clip_image, B, S, f.c_embed, f.splitk, st));
+    RET_IF(launch_silu(f.c_embed, f.c_silu, (int64_t)B * S * cc, st));
+
+    // per AttnBlock: kv = kv_mapper(c_embed) (src/modules.py:77), then K|V = kv . in_proj_weight[c:3c]^T + in_proj_bias[c:3c]
+    auto do_block = [&](const Block& b) -> int {
+        if (b.type != BT_ATTN) return PAELLA_OK;
+        const int ch = b.c;
+        GemmArgs g1 = gemm_args(f.c_silu, cc, T(m, b.prefix + ".kv_mapper.1.weight"), cc, f.kvm, ch, B * S, ch, cc);
+        g1.ep.bias = T(m, b.prefix + ".kv_mapper.1.bias");
+        RET_IF(launch_gemm(g1, f.splitk, skb, st));
+        float* dst = (float*)cond_out + cond_offset_floats(m, b.attn_index, B, S);
+        GemmArgs g2 = gemm_args(f.kvm, ch, T(m, b.prefix + ".attention.attn.in_proj_weight") + (size_t)ch * ch, ch, dst, 2 * ch, B * S,
+                                2 * ch, ch);
+        g2.ep.bias = T(m, b.prefix + ".attention.attn.in_proj_bias") + ch;
+        RET_IF(launch_gemm(g2, f.splitk, skb, st));
+        return PAELLA_OK;
+    };
+    for (const Block& b : m->down) RET_IF(do_block(b));
+    for (const Block& b : m->up) RET_IF(do_block(b));
+    return PAELLA_OK;
+}
+
+// ---------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------
+struct FwdCtx {
+    const paella_unet* m;
+    hipStream_t st;
+    FwdBuffers f;
+    int B, H, W, S;
+    const float* cond;
+    const float* attn_w;
+    int n_aw;
+};
+
+// ResBlock / FeedForwardBlock (reference src/modules.py:43-62, 82-96); x is updated in place
+static int run_mlp_block(FwdCtx& cx, const Block& b, float* x, const float* skip, int h, int w) {
+    const paella_unet* m = cx.m;
+    const int ch = b.c;
+    const int64_t rows = (int64_t)cx.B * h * w;
+    const int rps = h * w;
+    if (b.type == BT_RES)
+        RET_IF(launch_dwconv_ln(x, skip, T(m, b.prefix + ".depthwise.weight"), T(m, b.prefix + ".depthwise.bias"), cx.f.h, cx.B, h, w, ch, 1e-6f, cx.st));
+    else
+        RET_IF(launch_layernorm(x, cx.f.h, rows, ch, 1e-6f, 1.f, 0.f, 0, 0, 0, cx.st));
+    GemmArgs g1 = gemm_args(cx.f.h, ch, T(m, b.prefix + ".channelwise.0.weight"), ch, cx.f.g, 4 * ch, (int)rows, 4 * ch, ch);
+    g1.ep.bias = T(m, b.prefix + ".channelwise.0.bias");
+    g1.ep.act = ACT_GELU;
+    RET_IF(launch_gemm(g1, cx.f.splitk, kSplitKBudget, cx.st));
+    RET_IF(launch_grn_scale(cx.f.g, T(m, b.prefix + ".channelwise.2.gamma"), cx.f.grn_scale, cx.f.grn_gx, cx.B, rps, 4 * ch, cx.st));
+    GemmArgs g2 = gemm_args(cx.f.g, 4 * ch, T(m, b.prefix + ".channelwise.4.weight"), 4 * ch, x, ch, (int)rows, ch, 4 * ch);
+    g2.a_scale = cx.f.grn_scale;
+    g2.a_shift = T(m, b.prefix + ".channelwise.2.beta");
+    g2.a_rows_per_sample = rps;
+    g2.ep.bias = T(m, b.prefix + ".channelwise.4.bias");
+    g2.ep.residual = x; g2.ep.ldr = ch;
+    if (b.fused_ts >= 0) {
+        g2.ep.ts = cx.f.ts + b.fused_ts; g2.ep.ts_stride = m->ts_total; g2.ep.rows_per_sample = rps;
+    }
+    RET_IF(launch_gemm(g2, cx.f.splitk, kSplitKBudget, cx.st));
+    return PAELLA_OK;
+}
+
+// AttnBlock (reference src/modules.py:65-79)
+static int run_attn_block(FwdCtx& cx, const Block& b, float* x, int h, int w) {
+    const paella_unet* m = cx.m;
+    const int ch = b.c;
+    const int64_t rows = (int64_t)cx.B * h * w;
+    const int nh = m->cfg.nhead[b.level];
+    const bool self = m->cfg.self_attn != 0;
+    RET_IF(launch_layernorm(x, cx.f.h, rows, ch, 1e-6f, 1.f, 0.f, 0, 0, 0, cx.st));
+    const int nq = self ? 3 * ch : ch;
+    GemmArgs gq = gemm_args(cx.f.h, ch, T(m, b.prefix + ".attention.attn.in_proj_weight"), ch, cx.f.g, nq, (int)rows, nq, ch);
+    gq.ep.bias = T(m, b.prefix + ".attention.attn.in_proj_bias");
+    RET_IF(launch_gemm(gq, cx.f.splitk, kSplitKBudget, cx.st));
+    const float* kv = cx.cond + cond_offset_floats(m, b.attn_index, cx.B, cx.S);
+    AttnArgs a;
+    a.q = cx.f.g; a.ldq = nq;
+    a.k_self = self ? cx.f.g + ch : nullptr; a.v_self = self ? cx.f.g + 2 * ch : nullptr; a.ld_self = nq;
+    a.k_cond = kv; a.v_cond = kv + ch; a.ld_cond = 2 * ch;
+    a.out = cx.f.h; a.ldo = ch;
+    a.B = cx.B; a.nhead = nh; a.D = ch / nh; a.Lq = h * w; a.Lself = self ? h * w : 0; a.Lcond = cx.S;
+    a.scale = 1.0f / sqrtf((float)(ch / nh));
+    a.key_weights = cx.attn_w; a.n_kw = cx.n_aw;
+    RET_IF(launch_attention(a, cx.st));
+    GemmArgs go = gemm_args(cx.f.h, ch, T(m, b.prefix + ".attention.attn.out_proj.weight"), ch, x, ch, (int)rows, ch, ch);
+    go.ep.bias = T(m, b.prefix + ".attention.attn.out_proj.bias");
+    go.ep.residual = x; go.ep.ldr = ch;
+    RET_IF(launch_gemm(go, cx.f.splitk, kSplitKBudget, cx.st));
+    return PAELLA_OK;
+}
+
+extern "C" int paella_unet_forward(paella_unet* m, const int64_t* tokens, const float* r, const void* cond, int B, int H, int W,
+                                   int S, const float* attn_weights, int n_attn_weights, float* logits_out, void* ws,
+                                   size_t ws_bytes, void* stream) {
+    if (!m || !m->finalized) { paella_set_error("model not finalized"); return PAELLA_ERR_STATE; }
+    if (!tokens || !r || !logits_out) { paella_set_error("null argument"); return PAELLA_ERR_ARG; }
+    const paella_unet_config& c = m->cfg;
+    const int p = c.patch_size;
+    const int div = p << (c.n_levels - 1);
+    if (B <= 0 || H <= 0 || W <= 0 || H % div || W % div) {
+        paella_set_error("token grid %dx%d must be a positive multiple of %d", H, W, div);
+        return PAELLA_ERR_ARG;
+    }
+    if (m->n_attn > 0 && (!cond || S <= 0)) { paella_set_error("conditioning cache missing"); return PAELLA_ERR_ARG; }
+    FwdCtx cx;
+    cx.m = m; cx.st = (hipStream_t)stream; cx.B = B; cx.H = H; cx.W = W; cx.S = S;
+    cx.cond = (const float*)cond; cx.attn_w = attn_weights; cx.n_aw = attn_weights ? n_attn_weights : 0;
+    Arena a(ws, ws_bytes);
+    carve_forward(m, a, B, H, W, S, cx.f);
+    if (!a.ok || !ws) { paella_set_error("workspace too small (%zu needed, %zu given)", a.off, ws_bytes); return PAELLA_ERR_WORKSPACE; }
+    hipStream_t st = cx.st;
+    FwdBuffers& f = cx.f;
+
+    // timestep embedding + all TimestepBlock mappers
+    if (m->ts_total > 0)
+        RET_IF(launch_timestep(r, m->freqs.p, m->ts_w.p, m->ts_b.p, f.ts, B, c.c_r, m->ts_total, 10000.0f, f.remb, st));
+
+    // in_mapper + PixelUnshuffle + embedding conv + LayerNorm2d   (src/modules.py:126-134,271)
+    const int h0 = H / p, w0 = W / p;
+    const int64_t n0 = (int64_t)B * h0 * w0;
+    RET_IF(launch_embed_ln_unshuffle(tokens, T(m, "in_mapper.0.weight"), f.h, B, H, W, c.c_in, p, c.num_labels, 1e-6f, st));
+    {
+        GemmArgs g = gemm_args(f.h, c.c_in * p * p, T(m, "embedding.1.weight"), c.c_in * p * p, f.g, c.c_hidden[0], (int)n0, c.c_hidden[0], c.c_in * p * p);
+        g.ep.bias = T(m, "embedding.1.bias");
+        RET_IF(launch_gemm(g, f.splitk, kSplitKBudget, st));
+        RET_IF(launch_layernorm(f.g, f.xl[0], n0, c.c_hidden[0], 1e-6f, 1.f, 0.f, 0, 0, 0, st));
+    }
+
+    // ---- down ----
+    float* x = f.xl[0];
+    int h = h0, w = w0;
+    for (const Block& b : m->down) {
+        switch (b.type) {
+            case BT_DOWN: {  // LayerNorm2d + Conv2d(k2,s2): LN fused with the space-to-depth gather, then a GEMM
+                const int64_t rows_in = (int64_t)B * h * w;
+                RET_IF(launch_layernorm(x, f.h, rows_in, b.c_from, 1e-6f, 1.f, 0.f, 1, h, w, st));
+                h >>= 1; w >>= 1;
+                GemmArgs g = gemm_args(f.h, 4 * b.c_from, T(m, b.prefix + ".1.weight"), 4 * b.c_from, f.xl[b.level], b.c_to, (int)(rows_in / 4), b.c_to, 4 * b.c_from);
+                g.ep.bias = T(m, b.prefix + ".1.bias");
+                RET_IF(launch_gemm(g, f.splitk, kSplitKBudget, st));
+                x = f.xl[b.level];
+                break;
+            }
+            case BT_RES: case BT_FF: RET_IF(run_mlp_block(cx, b, x, nullptr, h, w)); break;
+            case BT_ATTN: RET_IF(run_attn_block(cx, b, x, h, w)); break;
+            case BT_TS:
+                if (b.ts_standalone)
+                    RET_IF(launch_scale_shift(x, f.ts + b.ts_offset, m->ts_total, (int64_t)B * h * w, h * w, b.c, st));
+                break;
+            default: break;
+        }
+    }
+    // ---- up ---- (x continues in place on the deepest level's buffer)
+    for (const Block& b : m->up) {
+        switch (b.type) {
+            case BT_UP: {  // LayerNorm2d + ConvTranspose2d(k2,s2): GEMM with N = 4*c_to and a depth-to-space store
+                const int64_t rows_in = (int64_t)B * h * w;
+                RET_IF(launch_layernorm(x, f.h, rows_in, b.c_from, 1e-6f, 1.f, 0.f, 0, 0, 0, st));
+                float* dst = f.xu[b.level - 1];
+                GemmArgs g = gemm_args(f.h, b.c_from, T(m, b.prefix + ".1.weight"), b.c_from, dst, b.c_to, (int)rows_in, 4 * b.c_to, b.c_from);
+                g.ep.bias = T(m, b.prefix + ".1.bias");
+                g.ep.store_mode = STORE_D2S; g.ep.sH = h; g.ep.sW = w; g.ep.sC = b.c_to; g.ep.n_seg_x = 2;
+                RET_IF(launch_gemm(g, f.splitk, kSplitKBudget, st));
+                h <<= 1; w <<= 1;
+                x = dst;
+                break;
+            }
+            case BT_RES: case BT_FF: RET_IF(run_mlp_block(cx, b, x, b.has_skip ? f.xl[b.level] : nullptr, h, w)); break;
+            case BT_ATTN: RET_IF(run_attn_block(cx, b, x, h, w)); break;
+            case BT_TS:
+                if (b.ts_standalone)
+                    RET_IF(launch_scale_shift(x, f.ts + b.ts_offset, m->ts_total, (int64_t)B * h * w, h * w, b.c, st));
+                break;
+            default: break;
+        }
+    }
+    // ---- clf + out_mapper (src/modules.py:179-187) ----
+    {
+        RET_IF(launch_layernorm(x, f.h, n0, c.c_hidden[0], 1e-6f, 1.f, 0.f, 0, 0, 0, st));
+        const int p2 = p * p;
+        GemmArgs g = gemm_args(f.h, c.c_hidden[0], T(m, "clf.1.weight"), c.c_hidden[0], f.g, c.c_out, (int)n0, c.c_out * p2, c.c_hidden[0]);
+        g.ep.bias = T(m, "clf.1.bias");
+        if (p == 2) { g.ep.store_mode = STORE_D2S; g.ep.sH = h0; g.ep.sW = w0; g.ep.sC = c.c_out; g.ep.n_seg_x = 2; }
+        RET_IF(launch_gemm(g, f.splitk, kSplitKBudget, st));
+        const int64_t nt = (int64_t)B * H * W;
+        RET_IF(launch_layernorm(f.g, f.h, nt, c.c_out, 1e-6f, 1.f, 0.f, 0, 0, 0, st));
+        GemmArgs go = gemm_args(f.h, c.c_out, T(m, "out_mapper.1.weight"), c.c_out, logits_out, c.num_labels, (int)nt, c.num_labels, c.c_out);
+        RET_IF(launch_gemm(go, f.splitk, kSplitKBudget, st));
+    }
+    return PAELLA_OK;
+}
+
+// ---------------------------------------------------------------------------
+// sampling tail / add_noise / single-op entry points
+// ---------------------------------------------------------------------------
+extern "C" int paella_sample_tail(const float* logits_c, const float* logits_u, int64_t rows, int L, float cfg, float one_minus_cfg,
+                                  float temperature, int mode, const float* noise_q, uint64_t seed, uint64_t offset,
+                                  const int64_t* init_noise, const float* mask_u, float t_next, int64_t* tokens_out,
+                                  int64_t* sampled_out, void* stream) {
+    if (!logits_c || !tokens_out) { paella_set_error("null argument"); return PAELLA_ERR_ARG; }
+    if (mode == 0 && !(temperature > 0.f)) { paella_set_error("temperature must be > 0 in categorical mode (use mode=1 for argmax)"); return PAELLA_ERR_ARG; }
+    TailArgs a;
+    a.logits_c = logits_c; a.logits_u = logits_u; a.rows = rows; a.L = L; a.cfg = cfg; a.one_minus_cfg = one_minus_cfg;
+    a.temperature = temperature; a.mode = mode; a.noise_q = noise_q; a.seed = seed; a.offset = offset;
+    a.init_noise = init_noise; a.mask_u = mask_u; a.t_next = t_next; a.tokens_out = tokens_out; a.sampled_out = sampled_out;
+    return launch_sample_tail(a, (hipStream_t)stream);
+}
+
+extern "C" int paella_add_noise(const int64_t* x, const float* t, const int64_t* mask_in, const int64_t* random_x, const float* rand_u,
+                                uint64_t seed, uint64_t offset, int num_labels, int B, int64_t per_sample, int64_t* x_out,
+                                int64_t* mask_out, void* stream) {
+    if (!x || !x_out || (!mask_in && !t)) { paella_set_error("null argument"); return PAELLA_ERR_ARG; }
+    return launch_add_noise(x, t, mask_in, random_x, rand_u, seed, offset, num_labels, B, per_sample, x_out, mask_out, (hipStream_t)stream);
+}
+
+extern "C" int paella_op_gemm(const float* A, const float* W, const float* bias, const float* residual, float* C, int M, int N, int K,
+                              int act, int tile_cfg, int splitk, void* ws, size_t ws_bytes, void* stream) {
+    GemmArgs g = gemm_args(A, K, W, K, C, N, M, N, K);
+    g.ep.bias = bias; g.ep.act = act; g.ep.residual = residual; g.ep.ldr = N;
+    return launch_gemm_cfg(g, tile_cfg, splitk, ws, ws_bytes, (hipStream_t)stream);
+}
+extern "C" int paella_op_layernorm(const float* x, float* y, int64_t rows, int C, float eps, void* stream) {
+    return launch_layernorm(x, y, rows, C, eps, 1.f, 0.f, 0, 0, 0, (hipStream_t)stream);
+}
+extern "C" int paella_op_dwconv_ln(const float* x, const float* skip, const float* w, const float* bias, float* y, int B, int H, int W,
+                                   int C, float eps, void* stream) {
+    return launch_dwconv_ln(x, skip, w, bias, y, B, H, W, C, eps, (hipStream_t)stream);
+}
+extern "C" int paella_op_grn_scale(const float* g, const float* gamma, float* scale, float* tmp, int B, int rows_per_sample, int C,
+                                   void* stream) {
+    return launch_grn_scale(g, gamma, scale, tmp, B, rows_per_sample, C, (hipStream_t)stream);
+}
+extern "C" int paella_op_attention(const float* q, const float* k_self, const float* v_self, const float* k_cond, const float* v_cond,
+                                   float* out, int B, int nhead, int D, int Lq, int Lself, int Lcond, const float* key_weights,
+                                   int n_kw, void* stream) {
+    AttnArgs a;
+    const int ld = nhead * D;
+    a.q = q; a.ldq = ld; a.k_self = k_self; a.v_self = v_self; a.ld_self = ld; a.k_cond = k_cond; a.v_cond = v_cond; a.ld_cond = ld;
+    a.out = out; a.ldo = ld; a.B = B; a.nhead = nhead; a.D = D; a.Lq = Lq; a.Lself = Lself; a.Lcond = Lcond;
+    a.scale = 1.0f / sqrtf((float)D); a.key_weights = key_weights; a.n_kw = key_weights ? n_kw : 0;
+    return launch_attention(a, (hipStream_t)stream);
+}

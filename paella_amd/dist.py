@@ -1,0 +1,136 @@
+"""Batch-sharded sampling across the GPUs of one node (one process per GPU, torch.distributed over RCCL/xGMI).
+
+Every op of the sampling path is per-sample (LayerNorm per position, GRN and attention within a sample, eval-mode
+BatchNorm), so the batch axis shards with no data-path collective.  The only exchange is ONE broadcast of the
+frozen conditioning (byt5 / clip / clip_image of the conditional and unconditional sets) from the rank that ran
+the text/image encoders, issued before step 0 -- packed into a single flat buffer so it is one RCCL call whose
+root fans out over all xGMI links.  The reference samples on a single device (sample() has no collective,
+src_distributed/utils.py:97-126); its only collectives are DDP's, for training (src_distributed/train.py:54).
+
+The functions here are plain host logic over torch.distributed and work with the gloo backend on CPU tensors
+(that is how tests/test_dist.py covers world_size 2); compute always goes through the HIP path.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(B, rank, world_size):
+    """Rows [lo, hi) of a batch of B owned by `rank` (contiguous, sizes differ by at most one)."""
+    base, rem = divmod(B, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def _flatten_inputs(inputs):
+    """dict(byt5, clip, clip_image[list]) -> (list of tensors, structure descriptor)"""
+    tensors, desc = [], []
+    for k in ("byt5", "clip", "clip_image"):
+        v = inputs.get(k) if inputs is not None else None
+        if v is None:
+            desc.append((k, None))
+        elif isinstance(v, (list, tuple)):
+            desc.append((k, [tuple(t.shape) for t in v]))
+            tensors.extend(v)
+        else:
+            desc.append((k, tuple(v.shape)))
+            tensors.append(v)
+    return tensors, desc
+
+
+def _unflatten(flat, desc, device):
+    out, off = {}, 0
+
+    def take(shape):
+        nonlocal off
+        n = 1
+        for d in shape:
+            n *= d
+        t = flat[off:off + n].view(shape)
+        off += n
+        return t
+
+    for k, d in desc:
+        if d is None:
+            out[k] = None
+        elif isinstance(d, list):
+            out[k] = [take(s) for s in d]
+        else:
+            out[k] = take(d)
+    return out
+
+
+def broadcast_conditioning(input_sets, src=0, device=None, group=None):
+    """Broadcast a list of conditioning dicts (e.g. [model_inputs, unconditional_inputs]) from `src` with ONE
+    tensor collective (plus one small object broadcast for the shapes).  Non-source ranks pass None."""
+    rank = dist.get_rank(group)
+    meta = [None]
+    flat = None
+    if rank == src:
+        all_tensors, descs = [], []
+        for s in input_sets:
+            ts, d = _flatten_inputs(s)
+            all_tensors.extend(ts)
+            descs.append(d)
+        device = all_tensors[0].device if device is None else torch.device(device)
+        flat = torch.cat([t.reshape(-1).float() for t in all_tensors]).to(device) if all_tensors else torch.zeros(0, device=device)
+        meta = [(descs, flat.numel())]
+    dist.broadcast_object_list(meta, src=src, group=group)
+    descs, numel = meta[0]
+    if rank != src:
+        if device is None:
+            raise ValueError("non-source ranks must pass device")
+        flat = torch.empty(numel, dtype=torch.float32, device=device)
+    dist.broadcast(flat, src=src, group=group)
+    out, off = [], 0
+    for d in descs:
+        n = 0
+        for _, shape in d:
+            for s in ([shape] if isinstance(shape, tuple) else (shape or [])):
+                m = 1
+                for x in s:
+                    m *= x
+                n += m
+        out.append(_unflatten(flat[off:off + n], d, flat.device))
+        off += n
+    return out
+
+
+def shard_inputs(inputs, lo, hi):
+    """Slice every conditioning tensor to this rank's rows."""
+    if inputs is None:
+        return None
+    out = {}
+    for k, v in inputs.items():
+        if v is None:
+            out[k] = None
+        elif isinstance(v, (list, tuple)):
+            out[k] = [t[lo:hi].contiguous() for t in v]
+        else:
+            out[k] = v[lo:hi].contiguous()
+    return out
+
+
+def sample_sharded(model, model_inputs, unconditional_inputs, latent_shape, src=0, group=None, gather=False, **kwargs):
+    """Batch-sharded `sample`: broadcast the conditioning once, sample this rank's rows, optionally all_gather.
+    `model_inputs` / `unconditional_inputs` are needed on rank `src` only.  kwargs go to paella_amd.sample."""
+    from .sampling import sample
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    device = next(model.parameters()).device
+    cond, uncond = broadcast_conditioning([model_inputs, unconditional_inputs] if rank == src else None, src=src,
+                                          device=device, group=group)
+    B, H, W = latent_shape
+    lo, hi = shard_bounds(B, rank, world)
+    local = None
+    if hi > lo:
+        local = sample(model, shard_inputs(cond, lo, hi), (hi - lo, H, W), unconditional_inputs=shard_inputs(uncond, lo, hi),
+                       device=device, **kwargs)
+    if not gather:
+        return local
+    sizes = [shard_bounds(B, r, world) for r in range(world)]
+    mx = max(h - l for l, h in sizes)
+    pad = torch.zeros(mx, H, W, dtype=torch.int64, device=device)
+    if local is not None:
+        pad[:hi - lo] = local
+    outs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(outs, pad, group=group)
+    return torch.cat([o[:h - l] for o, (l, h) in zip(outs, sizes)], dim=0)

@@ -1,0 +1,184 @@
+"""Paella's iterative token-denoising sampler on MI355X.
+
+Host mirror of the reference's two `sample()` functions:
+  * `sample`             -- src/utils.py:35-55          (model, model_inputs, latent_shape, unconditional_inputs=None, ...)
+  * `sample_distributed` -- src_distributed/utils.py:97-126 (model, model_inputs, unconditional_inputs, latent_shape, init_x=None, ...)
+Both drive the same core loop.  The loop itself is host code (a dozen lines, as in the reference); everything
+it calls is a HIP kernel: `Paella.prepare_cond` once per call (step-invariant conditioning work hoisted out of
+the loop), `Paella.forward_prepared` per step with the conditional and unconditional rows batched into one
+2B-row evaluation when their conditioning shapes agree (the reference runs two forwards, src/utils.py:44,46),
+and one fused tail kernel per step for CFG mix -> temperature -> softmax -> categorical draw -> renoise.
+
+Noise: with `noise="torch"` (default) the random numbers are drawn from torch's generator with the same calls in
+the same order as the reference (randint for the start tokens; per step `exponential_` for the multinomial draw
+-- torch.multinomial(p, 1) is argmax(p / Exp(1)) -- and `rand` for the renoise mask), so under the same seed the
+result equals the reference's whenever the logits agree.  `noise="philox"` generates all per-step noise inside
+the tail kernel (Philox4x32-10 keyed by `seed`), which removes the [B*H*W, num_labels] noise tensor.
+
+Extension (not reference behaviour): a step temperature of 0 selects argmax of the mixed logits.
+"""
+import torch
+
+from . import _lib
+from .modules import Paella
+
+
+def linspace_schedule(start, end, n):
+    """torch.linspace(start, end, n) as python floats of the fp32 values (what the reference multiplies by)."""
+    return [float(v) for v in torch.linspace(start, end, n)]
+
+
+def _same_cond_layout(a, b):
+    if a is None or b is None:
+        return False
+    for k in ("byt5", "clip", "clip_image"):
+        va, vb = a.get(k), b.get(k)
+        if (va is None) != (vb is None):
+            return False
+        if va is None:
+            continue
+        if isinstance(va, (list, tuple)) != isinstance(vb, (list, tuple)):
+            return False
+        if isinstance(va, (list, tuple)):
+            if len(va) != len(vb) or any(x.shape != y.shape for x, y in zip(va, vb)):
+                return False
+        elif va.shape != vb.shape:
+            return False
+    return True
+
+
+def _cat_inputs(a, b):
+    out = {}
+    for k in ("byt5", "clip", "clip_image"):
+        va, vb = a.get(k), b.get(k)
+        if va is None:
+            out[k] = None
+        elif isinstance(va, (list, tuple)):
+            out[k] = [torch.cat([x, y], dim=0) for x, y in zip(va, vb)]
+        else:
+            out[k] = torch.cat([va, vb], dim=0)
+    return out
+
+
+def _tail(logits_c, logits_u, rows, L, cfg, omc, temperature, mode, noise_q, seed, offset, init_noise, mask_u, t_next, out):
+    lib = _lib.load()
+    dev = logits_c.device
+    with torch.cuda.device(dev):
+        _lib.check(lib.paella_sample_tail(_lib.ptr(logits_c), _lib.ptr(logits_u), rows, L, cfg, omc, temperature, mode,
+                                          _lib.ptr(noise_q), seed, offset, _lib.ptr(init_noise), _lib.ptr(mask_u), t_next,
+                                          _lib.ptr(out), None, _lib.stream_ptr(dev)))
+
+
+def _sample_core(model, model_inputs, unconditional_inputs, latent_shape, init_x, steps, renoise_steps, t_list, temperatures,
+                 cfgs, device, noise="torch", seed=0, attn_weights=None):
+    """cfgs: per-step list of (cfg_fp32, one_minus_cfg_fp32) or None (no guidance at that step)."""
+    explicit = isinstance(noise, dict)  # parity tests: {"init_noise": [B,H,W], "q": [rows,L] per step, "u": [B,H,W] per step}
+    if not explicit and noise not in ("torch", "philox"):
+        raise ValueError("noise must be 'torch', 'philox' or a dict of explicit noise tensors")
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError("paella_amd.sample runs on a HIP device only (got device=%s); there is no CPU path" % device)
+    _lib.load()
+    B, H, W = (int(v) for v in latent_shape)
+    L = model.num_labels
+    rows = B * H * W
+    native = isinstance(model, Paella)
+    with torch.inference_mode():
+        if explicit:
+            init_noise = noise["init_noise"].to(device=device, dtype=torch.int64).contiguous()
+        else:
+            init_noise = torch.randint(0, L, size=(B, H, W), device=device)
+        sampled = init_noise.clone() if init_x is None else init_x.to(device=device, dtype=torch.int64).contiguous()
+        any_cfg = any(c is not None for c in cfgs)
+        batched = False
+        if native:
+            if any_cfg and _same_cond_layout(model_inputs, unconditional_inputs):
+                cond_both = model.prepare_cond(**_cat_inputs(model_inputs, unconditional_inputs))
+                batched = True
+                logits2 = torch.empty(2 * B, H, W, L, dtype=torch.float32, device=device)
+            if not batched or not all(c is not None for c in cfgs):
+                cond_c = model.prepare_cond(**model_inputs)
+                cond_u = model.prepare_cond(**unconditional_inputs) if any_cfg and not batched else None
+            logits_c = torch.empty(B, H, W, L, dtype=torch.float32, device=device)
+            logits_u = torch.empty(B, H, W, L, dtype=torch.float32, device=device) if any_cfg and not batched else None
+        out = torch.empty(B, H, W, dtype=torch.int64, device=device)
+        for i in range(steps):
+            r = torch.full((B,), t_list[i], dtype=torch.float32, device=device)
+            use_cfg = cfgs[i] is not None
+            if native:
+                if use_cfg and batched:
+                    model.forward_prepared(torch.cat([sampled, sampled], dim=0), torch.cat([r, r]), cond_both,
+                                           attn_weights=attn_weights, out=logits2)
+                    lc, lu = logits2[:B], logits2[B:]
+                else:
+                    model.forward_prepared(sampled, r, cond_c, attn_weights=attn_weights, out=logits_c)
+                    lc, lu = logits_c, None
+                    if use_cfg:
+                        model.forward_prepared(sampled, r, cond_u, attn_weights=attn_weights, out=logits_u)
+                        lu = logits_u
+            else:  # any other callable with the reference's signature; logits come back [B, L, H, W]
+                lc = model(sampled, r, **model_inputs).permute(0, 2, 3, 1).float().contiguous()
+                lu = model(sampled, r, **unconditional_inputs).permute(0, 2, 3, 1).float().contiguous() if use_cfg else None
+            temp = temperatures[i]
+            mode = 1 if temp == 0 else 0
+            noise_q = None
+            if explicit and mode == 0:
+                noise_q = noise["q"][i].to(device=device, dtype=torch.float32).contiguous()
+            elif noise == "torch" and mode == 0:
+                # what torch.multinomial(scores, 1) draws internally: q = empty_like(scores).exponential_(1)
+                # in the memory order of the reference's `scores.permute(0,2,3,1).reshape(-1, L)`: row-major copy for
+                # B > 1, but a column-major VIEW of the NCHW softmax output for B == 1
+                if B == 1:
+                    noise_q = torch.empty(L, rows, dtype=torch.float32, device=device).exponential_(1).t().contiguous()
+                else:
+                    noise_q = torch.empty(rows, L, dtype=torch.float32, device=device).exponential_(1)
+            renoise = i < renoise_steps
+            mask_u = None
+            if renoise and explicit:
+                mask_u = noise["u"][i].to(device=device, dtype=torch.float32).contiguous()
+            elif renoise and noise == "torch":
+                mask_u = torch.rand(B, H, W, dtype=torch.float32, device=device)  # == torch.rand_like(x.float())
+            cfg, omc = cfgs[i] if use_cfg else (1.0, 0.0)
+            _tail(lc, lu, rows, L, cfg, omc, temp if mode == 0 else 1.0, mode, noise_q, seed, i,
+                  init_noise if renoise else None, mask_u, t_list[i + 1] if renoise else 0.0, out)
+            sampled = out  # the tail never reads `sampled`, so one output buffer is enough (stream-ordered reuse)
+    return sampled
+
+
+def sample(model, model_inputs, latent_shape, unconditional_inputs=None, steps=12, renoise_steps=11, temperature=(1.0, 0.2),
+           cfg=8.0, t_start=1.0, t_end=0.0, device="cuda", *, noise="torch", seed=0, attn_weights=None):
+    """Drop-in for reference src/utils.py:35 `sample` (same positional order and defaults)."""
+    if cfg and unconditional_inputs is None:
+        # the reference raises TypeError at src/utils.py:46 (`**None`); keep the failure, make it readable
+        raise TypeError("cfg=%r requires unconditional_inputs" % (cfg,))
+    t_list = linspace_schedule(t_start, t_end, steps + 1)
+    temperatures = linspace_schedule(temperature[0], temperature[1], steps)
+    if cfg:
+        # `logits * cfg + logits_u * (1 - cfg)` with python-float cfg: both scalars are rounded to fp32 by torch
+        pair = (float(torch.tensor(float(cfg), dtype=torch.float32)), float(torch.tensor(1.0 - float(cfg), dtype=torch.float32)))
+        cfgs = [pair] * steps
+    else:
+        cfgs = [None] * steps
+    return _sample_core(model, model_inputs, unconditional_inputs, latent_shape, None, steps, renoise_steps, t_list, temperatures,
+                        cfgs, device, noise=noise, seed=seed, attn_weights=attn_weights)
+
+
+def sample_distributed(model, model_inputs, unconditional_inputs, latent_shape, init_x=None, steps=12, renoise_steps=None,
+                       temperature=(0.7, 0.3), cfg=(8.0, 8.0), t_start=1.0, t_end=0.0, sampling_conditional_steps=None, *,
+                       noise="torch", seed=0, attn_weights=None):
+    """Drop-in for reference src_distributed/utils.py:97 `sample` (init_x, cfg schedule, conditional-step cutoff)."""
+    device = unconditional_inputs["byt5"].device
+    if sampling_conditional_steps is None:
+        sampling_conditional_steps = steps
+    if renoise_steps is None:
+        renoise_steps = steps - 1
+    t_list = linspace_schedule(t_start, t_end, steps + 1)
+    temperatures = linspace_schedule(temperature[0], temperature[1], steps)
+    cfgs = [None] * steps
+    if cfg is not None:
+        sched = torch.linspace(cfg[0], cfg[1], steps)
+        for i in range(min(steps, sampling_conditional_steps)):
+            # `logits * cfgs[i] + logits_u * (1 - cfgs[i])` with a 0-dim fp32 tensor: (1 - cfg) is computed in fp32
+            cfgs[i] = (float(sched[i]), float(1 - sched[i]))
+    return _sample_core(model, model_inputs, unconditional_inputs, latent_shape, init_x, steps, renoise_steps, t_list, temperatures,
+                        cfgs, device, noise=noise, seed=seed, attn_weights=attn_weights)

@@ -1,0 +1,97 @@
+"""CPU: host-side logic of the drop-in surface (state-dict layout, schedules, fail-loud behaviour off-GPU)."""
+import numpy as np
+import pytest
+import torch
+
+import paella_amd
+from oracle import golden_configs as G
+from paella_amd import sampling, synth
+from paella_amd.dist import shard_bounds
+
+
+def _keys(module):
+    return sorted(k + ":" + ",".join(str(d) for d in v.shape) for k, v in module.state_dict().items())
+
+
+@pytest.mark.parametrize("name,cfg", [("unet_tiny_forward", G.UNET_TINY), ("unet_mid_forward", G.UNET_MID), ("unet_variant_forward", G.UNET_VARIANT)])
+def test_unet_state_dict_matches_reference(golden, name, cfg):
+    """Key names and shapes equal those enumerated from the live reference instance (stored with the fixture)."""
+    m = paella_amd.Paella(**cfg)
+    assert _keys(m) == sorted(golden(name)["keys"].tolist())
+
+
+@pytest.mark.parametrize("name,cfg", [("vq_tiny_f4", G.VQ_TINY_F4), ("vq_tiny_f8", G.VQ_TINY_F8)])
+def test_vqgan_state_dict_matches_reference(golden, name, cfg):
+    assert _keys(paella_amd.VQModel(**cfg)) == sorted(golden(name)["keys"].tolist())
+
+
+def test_default_block_layout():
+    # default blocks=[6,16,6] / level_config=['CT','CTA','CTA'], checked on a narrow model
+    cfg = G.UNET_1B
+    tiny = paella_amd.Paella(**dict(cfg, c_hidden=[8, 16, 16], nhead=[-1, 1, 1], c_in=8, c_out=8, num_labels=16, c_cond=16,
+                                    clip_embd=8, byt5_embd=8))
+    assert len(tiny.down_blocks[1]) == 1 + 16 * 3 and len(tiny.up_blocks[0]) == 6 * 3 + 1
+    assert paella_amd.DenoiseUNet is paella_amd.Paella
+
+
+def test_reference_init_semantics():
+    m = paella_amd.Paella(**G.UNET_TINY)
+    sd = m.state_dict()
+    assert sd["clf.1.weight"].abs().max() == 0  # logits identically zero at init, as in the reference
+    assert all(v.abs().max() == 0 for k, v in sd.items() if k.endswith(".mapper.weight") and "byt5" not in k and "clip" not in k)
+    assert torch.equal(sd["out_mapper.1.weight"][:, :, 0, 0], sd["in_mapper.0.weight"])
+    synth.randomize_(m, seed=1)
+    assert m.state_dict()["clf.1.weight"].abs().max() > 0
+
+
+def test_fails_loudly_off_gpu():
+    m = paella_amd.Paella(**G.UNET_TINY)
+    x = torch.zeros(1, 8, 8, dtype=torch.long)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        m(x, torch.zeros(1), torch.zeros(1, 2, 40))
+    with pytest.raises(RuntimeError, match="HIP device"):
+        m.add_noise(x, torch.zeros(1))
+    with pytest.raises(RuntimeError, match="HIP device"):
+        paella_amd.sample(m, {"byt5": torch.zeros(1, 2, 40)}, (1, 8, 8), unconditional_inputs={"byt5": torch.zeros(1, 2, 40)}, device="cpu")
+    v = paella_amd.VQModel(**G.VQ_TINY_F4)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        v.decode_indices(x)
+
+
+def test_schedules_match_torch_linspace():
+    assert sampling.linspace_schedule(1.0, 0.0, 9) == [float(v) for v in torch.linspace(1.0, 0.0, 9)]
+    assert sampling.linspace_schedule(1.0, 0.2, 8)[-1] == float(torch.tensor(0.2))
+
+
+def test_sample_signatures_match_reference():
+    import inspect
+    s = inspect.signature(paella_amd.sample)
+    assert list(s.parameters)[:11] == ["model", "model_inputs", "latent_shape", "unconditional_inputs", "steps", "renoise_steps",
+                                       "temperature", "cfg", "t_start", "t_end", "device"]
+    assert s.parameters["steps"].default == 12 and s.parameters["renoise_steps"].default == 11
+    assert s.parameters["temperature"].default == (1.0, 0.2) and s.parameters["cfg"].default == 8.0
+    d = inspect.signature(paella_amd.sample_distributed)
+    assert list(d.parameters)[:12] == ["model", "model_inputs", "unconditional_inputs", "latent_shape", "init_x", "steps",
+                                       "renoise_steps", "temperature", "cfg", "t_start", "t_end", "sampling_conditional_steps"]
+    assert d.parameters["temperature"].default == (0.7, 0.3) and d.parameters["cfg"].default == (8.0, 8.0)
+    f = inspect.signature(paella_amd.Paella.forward)
+    assert list(f.parameters)[:7] == ["self", "x", "r", "byt5", "clip", "clip_image", "x_cat"]
+    with pytest.raises(TypeError):  # reference: cfg=8.0 with unconditional_inputs=None raises TypeError (src/utils.py:46)
+        paella_amd.sample(None, {}, (1, 8, 8))
+
+
+def test_shard_bounds_partition():
+    for B in (1, 7, 8, 64, 255):
+        for w in (1, 2, 4, 8):
+            spans = [shard_bounds(B, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == B
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def test_synth_weights_are_deterministic():
+    m = paella_amd.Paella(**G.UNET_TINY)
+    a = synth.synth_state_dict(m.state_dict(), seed=0, n_blocks=4)
+    b = synth.synth_state_dict(m.state_dict(), seed=0, n_blocks=4)
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    assert synth.checksum(a) == synth.checksum(b)
