@@ -172,6 +172,13 @@ int paella_op_attention(const float* q, const float* k_self, const float* v_self
                         const float* v_cond, float* out, int B, int nhead, int D, int Lq, int Lself, int Lcond,
                         const float* key_weights, int n_kw, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Measurement hook (bench.py roofline line): when enabled, every dense-contraction launch is bracketed by HIP
+ * events on its stream; collect() returns the summed duration, algorithmic FLOPs and bytes since enable(1).
+ * ---------------------------------------------------------------------------------------------- */
+int paella_prof_enable(int on);
+int paella_prof_collect(double* total_ms, double* total_flops, double* total_bytes, int64_t* launches);
+
 #ifdef __cplusplus
 }
 #endif

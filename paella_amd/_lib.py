@@ -66,6 +66,8 @@ SIGNATURES = {
     "paella_vqgan_encode": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_size_t, c_void_p]),
     "paella_vqgan_quantize_rows": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "paella_prof_enable": (c_int, [c_int]),
+    "paella_prof_collect": (c_int, [POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int64)]),
     "paella_op_gemm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                c_void_p, c_size_t, c_void_p]),
     "paella_op_layernorm": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]),

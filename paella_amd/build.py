@@ -34,10 +34,12 @@ def _stale(target, deps):
 
 def build(force=False, verbose=False):
     """Compile every HIP translation unit for gfx950 and link the shared library. Returns its path."""
+    headers = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
+    if not force and not _stale(LIB, [os.path.join(CSRC, s) for s in SOURCES] + headers):
+        return LIB  # prebuilt library (e.g. shipped to the GPU box) is newer than every source
     hipcc = _hipcc()
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
     jobs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)

@@ -18,6 +18,7 @@
 //    consecutive inside one XCD so the panel is fetched from HBM once and re-read from that XCD's L2.
 #include "common.h"
 #include <stdio.h>
+#include <vector>
 
 __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
@@ -286,7 +287,67 @@ static void choose_config(int M, int N, int K, size_t ws_bytes, int* cfg_out, in
     *split_out = bs;
 }
 
+// ---------------------------------------------------------------------------
+// optional per-launch timing (HIP events on the launch stream) for bench.py's roofline line
+// ---------------------------------------------------------------------------
+struct GemmProf {
+    bool on = false;
+    std::vector<hipEvent_t> pool;   // events, used pairwise
+    size_t used = 0;
+    std::vector<double> flops, bytes;
+};
+static GemmProf g_prof;
+
+static int launch_gemm_cfg_impl(const GemmArgs& g, int cfg, int splitk, void* ws, size_t ws_bytes, hipStream_t st);
+
 int launch_gemm_cfg(const GemmArgs& g, int cfg, int splitk, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (!g_prof.on) return launch_gemm_cfg_impl(g, cfg, splitk, ws, ws_bytes, st);
+    if (g_prof.used + 2 > g_prof.pool.size()) {
+        for (int i = 0; i < 2; ++i) {
+            hipEvent_t e;
+            HIP_CHECK_RET(hipEventCreate(&e));
+            g_prof.pool.push_back(e);
+        }
+    }
+    hipEvent_t e0 = g_prof.pool[g_prof.used], e1 = g_prof.pool[g_prof.used + 1];
+    HIP_CHECK_RET(hipEventRecord(e0, st));
+    const int rc = launch_gemm_cfg_impl(g, cfg, splitk, ws, ws_bytes, st);
+    HIP_CHECK_RET(hipEventRecord(e1, st));
+    g_prof.used += 2;
+    g_prof.flops.push_back(2.0 * g.M * g.N * g.K);
+    g_prof.bytes.push_back(4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N));
+    return rc;
+}
+
+extern "C" int paella_prof_enable(int on) {
+    g_prof.on = on != 0;
+    g_prof.used = 0;
+    g_prof.flops.clear();
+    g_prof.bytes.clear();
+    return PAELLA_OK;
+}
+
+// Sums the event-timed GEMM launches recorded since paella_prof_enable(1) (synchronises on the recorded events).
+extern "C" int paella_prof_collect(double* total_ms, double* total_flops, double* total_bytes, int64_t* launches) {
+    double ms = 0, fl = 0, by = 0;
+    const size_t n = g_prof.used / 2;
+    for (size_t i = 0; i < n; ++i) {
+        HIP_CHECK_RET(hipEventSynchronize(g_prof.pool[2 * i + 1]));
+        float t = 0.f;
+        HIP_CHECK_RET(hipEventElapsedTime(&t, g_prof.pool[2 * i], g_prof.pool[2 * i + 1]));
+        ms += t; fl += g_prof.flops[i]; by += g_prof.bytes[i];
+    }
+    if (total_ms) *total_ms = ms;
+    if (total_flops) *total_flops = fl;
+    if (total_bytes) *total_bytes = by;
+    if (launches) *launches = (int64_t)n;
+    g_prof.used = 0;
+    g_prof.flops.clear();
+    g_prof.bytes.clear();
+    return PAELLA_OK;
+}
+
+static int launch_gemm_cfg_impl(const GemmArgs& g, int cfg, int splitk, void* ws, size_t ws_bytes, hipStream_t st) {
     if (g.M <= 0 || g.N <= 0) return PAELLA_OK;
     if ((g.K & 3) || (g.N & 3) || (g.lda & 3) || (g.ldw & 3) || (g.ldc & 3 && g.ep.store_mode != STORE_PIXSHUF_NCHW)) {
         paella_set_error("gemm: K, N, lda, ldw, ldc must be multiples of 4 (M=%d N=%d K=%d lda=%d ldw=%d ldc=%d)",

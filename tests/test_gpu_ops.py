@@ -1,0 +1,216 @@
+"""GPU: single-kernel parity through the C ABI (paella_op_*) against plain torch CPU math on the same seeded inputs."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import paella_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib(built_lib):
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return built_lib
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _st():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _check(lib, rc):
+    assert rc == 0, lib.paella_last_error()
+
+
+GEMM_SHAPES = [(512, 2560, 640), (512, 640, 2560), (128, 5120, 1280), (128, 1280, 5120), (32, 3840, 1280), (32, 1280, 1280),
+               (1, 4096, 1024), (2, 1024, 48), (1024, 8192, 256), (1024, 384, 4), (77, 132, 36), (300, 12, 96), (16, 64, 2048)]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm_heuristic(lib, M, N, K):
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    bias = torch.randn(N, generator=g)
+    R = torch.randn(M, N, generator=g)
+    ref = (F.gelu(A.double() @ W.double().t() + bias.double()) + R.double()).float()
+    Ad, Wd, bd, Rd = A.cuda(), W.cuda(), bias.cuda(), R.cuda()
+    C = torch.empty(M, N, device="cuda")
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    _check(lib, lib.paella_op_gemm(_p(Ad), _p(Wd), _p(bd), _p(Rd), _p(C), M, N, K, 1, -1, 1, _p(ws), ws.numel(), _st()))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(C.cpu().numpy(), ref.numpy(), atol=2e-5 * max(1, K ** 0.5 / 8), rtol=1e-5)
+
+
+@pytest.mark.parametrize("cfg", range(9))
+@pytest.mark.parametrize("splitk", [1, 3])
+def test_gemm_every_tile_config(lib, cfg, splitk):
+    M, N, K = 200, 328, 416  # ragged in every dimension
+    g = torch.Generator().manual_seed(cfg * 10 + splitk)
+    # asymmetric operands catch transposed fragments (guide rule 16)
+    A = torch.randn(M, K, generator=g) + torch.arange(K)[None, :] * 0.01
+    W = torch.randn(N, K, generator=g) + torch.arange(N)[:, None] * 0.02
+    ref = (A.double() @ W.double().t()).float()
+    C = torch.full((M, N), float("nan"), device="cuda")
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    Ad, Wd = A.cuda(), W.cuda()  # keep the device copies alive: a temporary's memory is recycled immediately
+    _check(lib, lib.paella_op_gemm(_p(Ad), _p(Wd), None, None, _p(C), M, N, K, 0, cfg, splitk, _p(ws), ws.numel(), _st()))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(C.cpu().numpy(), ref.numpy(), atol=1e-3, rtol=2e-5)
+
+
+def test_gemm_is_run_to_run_deterministic(lib):
+    M, N, K = 128, 1280, 5120
+    g = torch.Generator().manual_seed(1)
+    A, W = torch.randn(M, K, generator=g).cuda(), torch.randn(N, K, generator=g).cuda()
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    outs = []
+    for _ in range(3):
+        C = torch.empty(M, N, device="cuda")
+        _check(lib, lib.paella_op_gemm(_p(A), _p(W), None, None, _p(C), M, N, K, 0, -1, 1, _p(ws), ws.numel(), _st()))
+        outs.append(C)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+@pytest.mark.parametrize("rows,C", [(7, 32), (512, 640), (128, 1280), (1024, 256), (33, 384), (5, 2048)])
+def test_layernorm(lib, rows, C):
+    g = torch.Generator().manual_seed(rows + C)
+    x = torch.randn(rows, C, generator=g) * 3 + 1
+    y = torch.empty(rows, C, device="cuda")
+    xd = x.cuda()
+    _check(lib, lib.paella_op_layernorm(_p(xd), _p(y), rows, C, 1e-6, _st()))
+    np.testing.assert_allclose(y.cpu().numpy(), F.layer_norm(x, (C,), eps=1e-6).numpy(), atol=3e-6, rtol=1e-5)
+
+
+@pytest.mark.parametrize("B,H,W,C,skip", [(2, 8, 8, 32, False), (1, 16, 16, 640, False), (2, 4, 4, 1280, True), (3, 5, 7, 64, True), (1, 1, 1, 32, False)])
+def test_dwconv_ln(lib, B, H, W, C, skip):
+    g = torch.Generator().manual_seed(B * H + C)
+    x = torch.randn(B, C, H, W, generator=g)
+    sk = torch.randn(B, C, H, W, generator=g) if skip else None
+    w = torch.randn(C, 2 if skip else 1, 3, 3, generator=g) * 0.3
+    b = torch.randn(C, generator=g) * 0.1
+    inp = x if sk is None else torch.cat([x, sk], 1)
+    ref = O.ln_channels(F.conv2d(inp, w, b, padding=1, groups=C)).permute(0, 2, 3, 1)
+    xn = x.permute(0, 2, 3, 1).contiguous().cuda()
+    skn = sk.permute(0, 2, 3, 1).contiguous().cuda() if skip else None
+    wk = w.permute(1, 2, 3, 0).contiguous().cuda()  # [J,3,3,C]
+    y = torch.empty(B, H, W, C, device="cuda")
+    bd = b.cuda()
+    _check(lib, lib.paella_op_dwconv_ln(_p(xn), _p(skn), _p(wk), _p(bd), _p(y), B, H, W, C, 1e-6, _st()))
+    np.testing.assert_allclose(y.cpu().numpy(), ref.numpy(), atol=2e-5, rtol=1e-5)
+
+
+def test_grn_scale(lib):
+    B, rows, C = 3, 64, 256
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, rows, C, generator=g)
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    ref = O.grn(x.view(B, 8, 8, C), gamma.view(1, 1, 1, C), beta.view(1, 1, 1, C)).view(B, rows, C)
+    scale = torch.empty(B, C, device="cuda")
+    tmp = torch.empty(B, C, device="cuda")
+    xd, gd = x.cuda(), gamma.cuda()
+    _check(lib, lib.paella_op_grn_scale(_p(xd), _p(gd), _p(scale), _p(tmp), B, rows, C, _st()))
+    got = x * scale.cpu()[:, None, :] + beta
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("B,nh,D,Lq,Ls,Lc,nkw", [(2, 4, 16, 16, 16, 9, 0), (1, 16, 80, 64, 64, 4, 0), (2, 16, 80, 16, 16, 4, 3),
+                                                 (1, 2, 32, 50, 0, 7, 0), (1, 4, 80, 100, 100, 37, 5), (2, 1, 128, 1, 1, 1, 0)])
+def test_attention(lib, B, nh, D, Lq, Ls, Lc, nkw):
+    g = torch.Generator().manual_seed(Lq * 3 + Lc)
+    C = nh * D
+    q = torch.randn(B, Lq, C, generator=g)
+    ks, vs = torch.randn(B, Ls, C, generator=g), torch.randn(B, Ls, C, generator=g)
+    kc, vc = torch.randn(B, Lc, C, generator=g), torch.randn(B, Lc, C, generator=g)
+    kw = torch.rand(nkw, generator=g) * 2 if nkw else None
+    k = torch.cat([ks, kc], 1).view(B, Ls + Lc, nh, D).permute(0, 2, 1, 3).double()
+    v = torch.cat([vs, vc], 1).view(B, Ls + Lc, nh, D).permute(0, 2, 1, 3).double()
+    qq = q.view(B, Lq, nh, D).permute(0, 2, 1, 3).double()
+    att = ((qq @ k.transpose(-1, -2)) / D ** 0.5).softmax(-1)
+    if nkw:
+        wts = torch.ones(Lq, Ls + Lc, dtype=torch.float64)
+        wts[:, -nkw:] = kw.double()
+        att = att * wts
+    ref = (att @ v).permute(0, 2, 1, 3).reshape(B, Lq, C).float()
+    out = torch.full((B, Lq, C), float("nan"), device="cuda")
+    qd, ksd, vsd, kcd, vcd = q.cuda(), ks.cuda(), vs.cuda(), kc.cuda(), vc.cuda()
+    kwd = kw.cuda() if nkw else None
+    _check(lib, lib.paella_op_attention(_p(qd), _p(ksd) if Ls else None, _p(vsd) if Ls else None, _p(kcd), _p(vcd), _p(out), B, nh, D,
+                                        Lq, Ls, Lc, _p(kwd), nkw, _st()))
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), atol=2e-5, rtol=1e-4)
+
+
+def test_attention_online_softmax_rescale_branch(lib):
+    """Spike one key far above the rest in a late tile so the running max jumps (guide rule 26)."""
+    B, nh, D, Lq, Lc = 1, 1, 16, 16, 70
+    g = torch.Generator().manual_seed(0)
+    q = torch.randn(B, Lq, D, generator=g)
+    kc, vc = torch.randn(B, Lc, D, generator=g), torch.randn(B, Lc, D, generator=g)
+    kc[0, 50] = q[0, 3] * 20
+    att = ((q.double() @ kc.double().transpose(-1, -2)) / D ** 0.5).softmax(-1)
+    ref = (att @ vc.double()).float()
+    out = torch.empty(B, Lq, D, device="cuda")
+    qd, kcd, vcd = q.cuda(), kc.cuda(), vc.cuda()
+    _check(lib, lib.paella_op_attention(_p(qd), None, None, _p(kcd), _p(vcd), _p(out), B, nh, D, Lq, 0, Lc, None, 0, _st()))
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), atol=2e-5, rtol=1e-4)
+
+
+def _tail(lib, lc, lu, cfg, omc, temp, mode, q, init_noise, u, t_next, seed=0, offset=0):
+    rows, L = lc.shape
+    out = torch.empty(rows, dtype=torch.int64, device="cuda")
+    pre = torch.empty(rows, dtype=torch.int64, device="cuda")
+    _check(lib, lib.paella_sample_tail(_p(lc), _p(lu), rows, L, cfg, omc, temp, mode, _p(q), seed, offset, _p(init_noise), _p(u), t_next,
+                                       _p(out), _p(pre), _st()))
+    torch.cuda.synchronize()
+    return out.cpu(), pre.cpu()
+
+
+def test_sample_tail_bit_exact_with_torch_noise(lib):
+    """CFG mix + temperature + softmax + categorical draw + renoise equals the reference arithmetic given the same noise."""
+    B, L, H, W = 2, 8192, 8, 8
+    g = torch.Generator().manual_seed(3)
+    lc, lu = torch.randn(B, L, H, W, generator=g), torch.randn(B, L, H, W, generator=g)
+    q = torch.empty(B * H * W, L).exponential_(1, generator=g)
+    u = torch.rand(B, H, W, generator=g)
+    init_noise = torch.randint(0, L, (B, H, W), generator=g)
+    cfg, omc, temp, t_next = 8.0, float(torch.tensor(1.0 - 8.0)), float(torch.tensor(0.6571)), 0.42
+    ref_tok = O.sample_tail(lc, lu, cfg, omc, temp, noise_q=q)
+    ref_out, _ = O.add_noise(ref_tok, torch.full((B,), t_next), L, random_x=init_noise, rand_u=u)
+    flat = lambda t: t.permute(0, 2, 3, 1).reshape(-1, L).contiguous().cuda()
+    lcd, lud, qd, ind, ud = flat(lc), flat(lu), q.cuda(), init_noise.view(-1).cuda(), u.view(-1).cuda()
+    out, pre = _tail(lib, lcd, lud, cfg, omc, temp, 0, qd, ind, ud, t_next)
+    assert torch.equal(pre.view(B, H, W), ref_tok)
+    assert torch.equal(out.view(B, H, W), ref_out)
+    # argmax mode (T = 0 extension) is bit-exact by construction
+    out_a, _ = _tail(lib, lcd, lud, cfg, omc, 1.0, 1, None, None, None, 0.0)
+    assert torch.equal(out_a.view(B, H, W), O.sample_tail(lc, lu, cfg, omc, 1.0, mode=1))
+    # no guidance
+    out_n, _ = _tail(lib, lcd, None, 1.0, 0.0, temp, 0, qd, None, None, 0.0)
+    assert torch.equal(out_n.view(B, H, W), O.sample_tail(lc, None, None, None, temp, noise_q=q))
+
+
+def test_sample_tail_philox_distribution(lib):
+    """In-kernel Philox draws follow softmax(logits / T): chi-square-style check on a small alphabet."""
+    L, rows = 8, 40000
+    logits = torch.tensor([0.0, 1.0, 2.0, -1.0, 0.5, 3.0, -2.0, 1.5])
+    lc = logits.repeat(rows, 1).cuda()
+    out, _ = _tail(lib, lc, None, 1.0, 0.0, 0.8, 0, None, None, None, 0.0, seed=123, offset=1)
+    freq = torch.bincount(out, minlength=L).double() / rows
+    p = (logits.double() / 0.8).softmax(-1)
+    assert (freq - p).abs().max() < 4 * (p * (1 - p) / rows).sqrt().max() + 1e-3
+    out2, _ = _tail(lib, lc, None, 1.0, 0.0, 0.8, 0, None, None, None, 0.0, seed=123, offset=1)
+    out3, _ = _tail(lib, lc, None, 1.0, 0.0, 0.8, 0, None, None, None, 0.0, seed=124, offset=1)
+    assert torch.equal(out, out2) and not torch.equal(out, out3)
+    # renoise mask frequency ~ t_next
+    init = torch.full((rows,), 7, dtype=torch.int64).cuda()
+    outm, pre = _tail(lib, lc, None, 1.0, 0.0, 0.8, 0, None, init, None, 0.3, seed=9)
+    frac = ((outm == 7) & (pre != 7)).double().sum() / (pre != 7).double().sum()
+    assert abs(float(frac) - 0.3) < 0.02
