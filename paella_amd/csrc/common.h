@@ -55,6 +55,7 @@ struct Epilogue {
     int sH, sW, sC;         // STORE_D2S / PIXSHUF: source grid (rows m=(b,y,x)), channels per segment
     int py, px;             // STORE_D2S: extra output offset (transposed-conv phase)
     int n_seg_x;            // STORE_D2S: segments along n are (dy,dx) with dx in [0,n_seg_x); 2 for k2s2, 1 for a phase
+    float* sumsq_out;       // optional [ceil(M/16), N]: per 16-row group, column sums of the stored values squared (GRN)
     int remap_in, remap_out, remap_off;  // STORE_PLAIN, remap_in > 0: out row = (m/remap_in)*remap_out + m%remap_in + remap_off
 };
 
@@ -62,7 +63,7 @@ static inline Epilogue make_epilogue() {
     Epilogue e;
     e.bias = nullptr; e.act = ACT_NONE; e.alpha = 1.f; e.residual = nullptr; e.ldr = 0;
     e.ts = nullptr; e.ts_stride = 0; e.rows_per_sample = 1; e.store_mode = STORE_PLAIN;
-    e.sH = e.sW = e.sC = 0; e.py = e.px = 0; e.n_seg_x = 2; e.remap_in = e.remap_out = e.remap_off = 0;
+    e.sH = e.sW = e.sC = 0; e.py = e.px = 0; e.n_seg_x = 2; e.remap_in = e.remap_out = e.remap_off = 0; e.sumsq_out = nullptr;
     return e;
 }
 
@@ -84,6 +85,8 @@ int launch_gemm(const GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t stream
 // Forces a specific tile config / split (for the autotuner and tests). cfg < 0 -> heuristic.
 int launch_gemm_cfg(const GemmArgs& g, int cfg, int splitk, void* ws, size_t ws_bytes, hipStream_t stream);
 size_t gemm_splitk_ws_bytes(int M, int N, int K);
+// weight-streaming kernel (gemm_ws.hip): tm_code 0..3 -> BM = 16,32,64,128; tn 1|2 -> BN = 64|128; in-launch split-K reduce
+int launch_gemm_ws(const GemmArgs& g, int tm_code, int tn, int splitk, void* ws, size_t ws_bytes, hipStream_t stream);
 
 // LayerNorm over the channel dimension of [rows, C]; no learned affine (eps 1e-6),
 // optional scalar affine y = ln(x)*(1+g0)+g1 (VQGAN), optional space-to-depth gather:

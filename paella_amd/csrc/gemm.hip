@@ -17,55 +17,9 @@
 //  * XCD-aware tile order: workgroup b runs on XCD b%8; tiles that share a weight panel are made
 //    consecutive inside one XCD so the panel is fetched from HBM once and re-read from that XCD's L2.
 #include "common.h"
+#include "gemm_device.h"
 #include <stdio.h>
 #include <vector>
-
-__device__ __forceinline__ float gelu_erf(float x) {
-    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
-}
-
-__device__ __forceinline__ void epilogue_store(const Epilogue& ep, float* __restrict__ C, int ldc, int N,
-                                               int m, int n, f32x4 v) {
-    if (ep.bias) v += *reinterpret_cast<const f32x4*>(ep.bias + n);
-    if (ep.act == ACT_GELU) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = gelu_erf(v[i]);
-    }
-    if (ep.alpha != 1.0f) v *= ep.alpha;
-    if (ep.residual) v += *reinterpret_cast<const f32x4*>(ep.residual + (size_t)m * ep.ldr + n);
-    if (ep.ts) {
-        const float* t = ep.ts + (size_t)(m / ep.rows_per_sample) * ep.ts_stride;
-        f32x4 a = *reinterpret_cast<const f32x4*>(t + n);
-        f32x4 b = *reinterpret_cast<const f32x4*>(t + N + n);
-        v = v * (1.0f + a) + b;
-    }
-    if (ep.store_mode == STORE_PLAIN) {
-        size_t orow = m;
-        if (ep.remap_in > 0) orow = (size_t)(m / ep.remap_in) * ep.remap_out + (m % ep.remap_in) + ep.remap_off;
-        *reinterpret_cast<f32x4*>(C + orow * ldc + n) = v;
-    } else {
-        const int hw = ep.sH * ep.sW;
-        const int b = m / hw;
-        const int rem = m - b * hw;
-        const int y = rem / ep.sW;
-        const int x = rem - y * ep.sW;
-        if (ep.store_mode == STORE_D2S) {
-            const int seg = n / ep.sC;
-            const int co = n - seg * ep.sC;
-            const int dy = seg / ep.n_seg_x;
-            const int dx = seg - dy * ep.n_seg_x;
-            const size_t orow = ((size_t)b * (2 * ep.sH) + 2 * y + dy + ep.py) * (2 * ep.sW) + 2 * x + dx + ep.px;
-            *reinterpret_cast<f32x4*>(C + orow * ldc + co) = v;
-        } else {  // STORE_PIXSHUF_NCHW: n = c*4 + dy*2 + dx -> out[b][c][2y+dy][2x+dx]
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int nn = n + i;
-                const int c = nn >> 2, dy = (nn >> 1) & 1, dx = nn & 1;
-                C[(((size_t)b * ep.sC + c) * (2 * ep.sH) + 2 * y + dy) * (2 * ep.sW) + 2 * x + dx] = v[i];
-            }
-        }
-    }
-}
 
 template <int WM, int WN, int TM, int TN, bool APRO>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g, int kslice, float* __restrict__ partial,
@@ -102,61 +56,62 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g, int kslice, fl
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    f32x4 ra[LA], rb[LB];
+    // Loads are unconditional from clamped in-bounds addresses and never select-masked in the steady state (a load
+    // under a lane condition, or a select on its result inside a conditional block, makes hipcc wait for it at once).
+    // Out-of-range rows only feed outputs that are never stored; the K tail is zeroed on the ACTIVATION side only.
+    f32x4 ra[LA], rb[LB], rs[APRO ? LA : 1], rt;
+    rt = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* aptr[LA];
+    const float* sptr[APRO ? LA : 1];
+    const float* bptr[LB];
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+        const int gmc = min(m0 + ldrow + i * 32, g.M - 1);
+        aptr[i] = g.A + (size_t)gmc * g.lda;
+        if (APRO) sptr[i] = g.a_scale + (size_t)(gmc / g.a_rows_per_sample) * g.K;
+    }
+#pragma unroll
+    for (int i = 0; i < LB; ++i) bptr[i] = g.W + (size_t)min(n0 + ldrow + i * 32, g.N - 1) * g.ldw;
 
     auto load_tile = [&](int k0) {
-        const int k = k0 + ldc4 * 4;
+        const int kc = min(k0 + ldc4 * 4, g.K - 4);
 #pragma unroll
         for (int i = 0; i < LA; ++i) {
-            const int row = ldrow + i * 32;
-            const int gm = m0 + row;
-            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (row < BM && gm < g.M && k < kend) {
-                v = *reinterpret_cast<const f32x4*>(g.A + (size_t)gm * g.lda + k);
-                if (APRO) {
-                    const int b = gm / g.a_rows_per_sample;
-                    const f32x4 s = *reinterpret_cast<const f32x4*>(g.a_scale + (size_t)b * g.K + k);
-                    const f32x4 t = *reinterpret_cast<const f32x4*>(g.a_shift + k);
-                    v = v * s + t;
-                }
-            }
-            ra[i] = v;
+            ra[i] = *reinterpret_cast<const f32x4*>(aptr[i] + kc);
+            if (APRO) rs[i] = *reinterpret_cast<const f32x4*>(sptr[i] + kc);
         }
+        if (APRO) rt = *reinterpret_cast<const f32x4*>(g.a_shift + kc);
 #pragma unroll
-        for (int i = 0; i < LB; ++i) {
-            const int row = ldrow + i * 32;
-            const int gn = n0 + row;
-            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (row < BN && gn < g.N && k < kend)
-                v = *reinterpret_cast<const f32x4*>(g.W + (size_t)gn * g.ldw + k);
-            rb[i] = v;
-        }
+        for (int i = 0; i < LB; ++i) rb[i] = *reinterpret_cast<const f32x4*>(bptr[i] + kc);
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, int k0) {
         float* As = smem + buf * (BM + BN) * BK;
         float* Bs = As + BM * BK;
+        const bool kok = k0 + ldc4 * 4 < kend;
 #pragma unroll
         for (int i = 0; i < LA; ++i) {
             const int row = ldrow + i * 32;
-            if (row < BM) *reinterpret_cast<f32x4*>(As + row * BK + ((ldc4 ^ (row & 7)) << 2)) = ra[i];
+            f32x4 v = ra[i];
+            if (APRO) v = v * rs[i] + rt;
+            if (!kok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (LA * 32 == BM || row < BM) *reinterpret_cast<f32x4*>(As + row * BK + ((ldc4 ^ (row & 7)) << 2)) = v;
         }
 #pragma unroll
         for (int i = 0; i < LB; ++i) {
             const int row = ldrow + i * 32;
-            if (row < BN) *reinterpret_cast<f32x4*>(Bs + row * BK + ((ldc4 ^ (row & 7)) << 2)) = rb[i];
+            if (LB * 32 == BN || row < BN) *reinterpret_cast<f32x4*>(Bs + row * BK + ((ldc4 ^ (row & 7)) << 2)) = rb[i];
         }
     };
 
     const int ntiles = (kend - kbeg + BK - 1) / BK;
-    if (ntiles > 0) {
-        load_tile(kbeg);
-        store_tile(0);
-    }
+    load_tile(kbeg);
+    store_tile(0, kbeg);
     __syncthreads();
 
     for (int t = 0; t < ntiles; ++t) {
         const int buf = t & 1;
-        if (t + 1 < ntiles) load_tile(kbeg + (t + 1) * BK);
+        load_tile(kbeg + (t + 1) * BK);
+        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch above the MFMA block (hipcc sinks it otherwise)
         const float* As = smem + buf * (BM + BN) * BK;
         const float* Bs = As + BM * BK;
 #pragma unroll
@@ -181,7 +136,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g, int kslice, fl
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][e], af[i][e], acc[i][j], 0, 0, 0);
         }
-        if (t + 1 < ntiles) store_tile(buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        store_tile(buf ^ 1, kbeg + (t + 1) * BK);
         __syncthreads();
     }
 
@@ -252,34 +208,28 @@ size_t gemm_splitk_ws_bytes(int M, int N, int K) {
     return (size_t)16 * M * N * sizeof(float);  // up to 16 slabs
 }
 
-// Cost model (cycles, arbitrary but consistent units) used to pick tile + split for a shape.
+// Tile / split-K choice.  Fitted to tools/gemm_tune.py sweeps on MI355X (gpurun_out/gemm_tune*.json): every variant
+// behaves like  t = fixed + flops / (157 TF * tile_eff * occupancy_fill) + slab traffic, with fixed ~4 us for one launch
+// and ~8 us when a split-K reduce launch follows; small tiles + enough workgroups (~5 per CU) win for skinny M.
 static void choose_config(int M, int N, int K, size_t ws_bytes, int* cfg_out, int* split_out) {
+    static const int cand[] = {1, 2, 4, 3, 5};
+    static const double eff[] = {0.72, 0.70, 0.66, 0.66, 0.62};
+    const double flops_us = 2.0 * M * N * K / 157.3e6;
     double best = 1e30;
-    int bc = 2, bs = 1;
-    for (int c = 0; c < kNumCfgs; ++c) {
+    int bc = 5, bs = 1;
+    for (int ci = 0; ci < 5; ++ci) {
+        const int c = cand[ci];
         const int BM = kCfgs[c].wm * kCfgs[c].tm * 16, BN = kCfgs[c].wn * kCfgs[c].tn * 16;
-        const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
-        const long tiles = (long)tm * tn;
-        const int lds = 2 * (BM + BN) * 32 * 4;
-        int occ = 160 * 1024 / lds;
-        if (occ > 4) occ = 4;
-        if (occ < 1) occ = 1;
+        const long tiles = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
         for (int S = 1; S <= 16; S *= 2) {
-            int ks = ((K + S - 1) / S + 31) / 32 * 32;
-            if (S > 1 && (ks < 128 || (size_t)S * M * N * 4 > ws_bytes)) break;
+            const int ks = ((K + S - 1) / S + 31) / 32 * 32;
+            if (S > 1 && (ks < 160 || (size_t)S * M * N * 4 > ws_bytes)) break;
             const int Seff = (K + ks - 1) / ks;
             const long wgs = tiles * Seff;
-            // per-workgroup time if it had a CU alone
-            const double mfma = (double)BM * BN * ks / 128.0;            // 256 flop/clk/CU
-            const double mem = (double)(BM + BN) * ks * 4.0 / 24.0;      // ~24 B/clk/CU sustained from L2/HBM
-            const double one = (mfma > mem ? mfma : mem) + 1500.0;       // + prologue/epilogue latency
-            // CU-rounds: `occ` co-resident workgroups share the CU's pipes
-            const long slots = 256L * occ;
-            const long rounds = (wgs + slots - 1) / slots;
-            const long last = wgs - (rounds - 1) * slots;                // workgroups in the last round
-            const double per_cu_last = (double)((last + 255) / 256);
-            double t = (rounds - 1) * one * occ + per_cu_last * one;
-            if (Seff > 1) t += 4000.0 + (double)Seff * M * N * 4.0 / 1500.0;  // reduce launch + slab traffic
+            double fill = wgs >= 768 ? 1.0 : (double)wgs / 768.0;
+            if (wgs > 1280) fill *= (double)wgs / (double)(((wgs + 1279) / 1280) * 1280);
+            double t = (Seff > 1 ? 8.0 : 4.0) + flops_us / (eff[ci] * fill);
+            if (Seff > 1) t += (double)Seff * M * N * 8.0 / 8.0e6;
             if (t < best) { best = t; bc = c; bs = Seff; }
         }
     }
@@ -360,6 +310,8 @@ static int launch_gemm_cfg_impl(const GemmArgs& g, int cfg, int splitk, void* ws
     }
     int S = splitk;
     if (cfg < 0) choose_config(g.M, g.N, g.K, ws ? ws_bytes : 0, &cfg, &S);
+    if (cfg >= 16 && cfg < 24) return launch_gemm_ws(g, (cfg - 16) >> 1, ((cfg - 16) & 1) + 1, S, ws, ws_bytes, st);
+    if (g.ep.sumsq_out) { paella_set_error("gemm: sumsq epilogue needs a weight-streaming config"); return PAELLA_ERR_ARG; }
     if (cfg >= kNumCfgs) { paella_set_error("gemm: bad tile config %d", cfg); return PAELLA_ERR_ARG; }
     if (S < 1) S = 1;
     int kslice = ((g.K + S - 1) / S + 31) / 32 * 32;

@@ -49,7 +49,7 @@ def test_gemm_heuristic(lib, M, N, K):
     np.testing.assert_allclose(C.cpu().numpy(), ref.numpy(), atol=2e-5 * max(1, K ** 0.5 / 8), rtol=1e-5)
 
 
-@pytest.mark.parametrize("cfg", range(9))
+@pytest.mark.parametrize("cfg", list(range(9)) + list(range(16, 24)))
 @pytest.mark.parametrize("splitk", [1, 3])
 def test_gemm_every_tile_config(lib, cfg, splitk):
     M, N, K = 200, 328, 416  # ragged in every dimension
@@ -64,6 +64,25 @@ def test_gemm_every_tile_config(lib, cfg, splitk):
     _check(lib, lib.paella_op_gemm(_p(Ad), _p(Wd), None, None, _p(C), M, N, K, 0, cfg, splitk, _p(ws), ws.numel(), _st()))
     torch.cuda.synchronize()
     np.testing.assert_allclose(C.cpu().numpy(), ref.numpy(), atol=1e-3, rtol=2e-5)
+
+
+@pytest.mark.parametrize("cfg", range(16, 24))
+def test_gemm_ws_split_reduce_is_repeatable(lib, cfg):
+    """In-launch split-K (last-arriver reduce): many back-to-back launches give bit-identical, correct results."""
+    M, N, K = 96, 640, 2560
+    g = torch.Generator().manual_seed(cfg)
+    A, W = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / 50
+    ref = (A.double() @ W.double().t()).float()
+    Ad, Wd = A.cuda(), W.cuda()
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    outs = []
+    for it in range(8):
+        C = torch.full((M, N), float("nan"), device="cuda")
+        _check(lib, lib.paella_op_gemm(_p(Ad), _p(Wd), None, None, _p(C), M, N, K, 0, cfg, 8, _p(ws), ws.numel(), _st()))
+        outs.append(C)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(outs[0].cpu().numpy(), ref.numpy(), atol=1e-4, rtol=2e-5)
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
 
 
 def test_gemm_is_run_to_run_deterministic(lib):

@@ -1,0 +1,85 @@
+"""Sweep (tile config, split-K) of the fp32 MFMA GEMM over the shapes of the sampling path and print TFLOP/s per variant.
+Usage (GPU box): python tools/gemm_tune.py [--out gpurun_out/gemm_tune.json]"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from paella_amd import _lib
+
+# (M, N, K, apro) for the 570M-class model at 32x32 tokens, cond+uncond batched (2 rows), plus batch-8 variants
+SHAPES = {
+    "L0 mlp1 512x2560x640": (512, 2560, 640), "L0 mlp2 512x640x2560": (512, 640, 2560),
+    "L1 mlp1 128x5120x1280": (128, 5120, 1280), "L1 mlp2 128x1280x5120": (128, 1280, 5120),
+    "L1 qkv 128x3840x1280": (128, 3840, 1280), "L1 out 128x1280x1280": (128, 1280, 1280),
+    "L2 mlp1 32x5120x1280": (32, 5120, 1280), "L2 mlp2 32x1280x5120": (32, 1280, 5120),
+    "L2 qkv 32x3840x1280": (32, 3840, 1280), "L2 out 32x1280x1280": (32, 1280, 1280),
+    "embed 512x640x1024": (512, 640, 1024), "down1 128x1280x2560": (128, 1280, 2560), "down2 32x1280x5120": (32, 1280, 5120),
+    "up2 32x5120x1280": (32, 5120, 1280), "up1 128x2560x1280": (128, 2560, 1280), "clf 512x1024x640": (512, 1024, 640),
+    "out 2048x8192x256": (2048, 8192, 256),
+    "b8 L0 mlp1 4096x2560x640": (4096, 2560, 640), "b8 L0 mlp2 4096x640x2560": (4096, 640, 2560),
+    "b8 L1 mlp1 1024x5120x1280": (1024, 5120, 1280), "b8 L1 mlp2 1024x1280x5120": (1024, 1280, 5120),
+    "b8 L2 mlp1 256x5120x1280": (256, 5120, 1280), "b8 L2 mlp2 256x1280x5120": (256, 1280, 5120),
+    "vq mlp1 1024x1536x384": (1024, 1536, 384), "vq mlp2 1024x384x1536": (1024, 384, 1536),
+    "vq mlp1 16384x384x96": (16384, 384, 96), "vq mlp2 16384x96x384": (16384, 96, 384),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=None)
+    ap.add_argument("--iters", type=int, default=30)
+    a = ap.parse_args()
+    lib = _lib.load()
+    st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ws = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+    results = {}
+    for name, (M, N, K) in SHAPES.items():
+        # cold weights without a flush kernel: rotate over enough distinct copies of W to exceed the 256 MiB MALL,
+        # exactly like consecutive layers of the model; activations stay warm.  One event pair brackets a whole
+        # rotation of back-to-back launches, so the figure includes the real launch boundaries.
+        ncopy = max(2, min(64, int(600e6 // (N * K * 4)) + 1))
+        A = torch.randn(M, K, device="cuda")
+        Ws = [torch.randn(N, K, device="cuda") for _ in range(ncopy)]
+        C = torch.empty(M, N, device="cuda")
+        row = {}
+        variants = [(-1, 1)] + [(c, s) for c in range(9) for s in (1, 2, 4, 8, 16)] + [(c, s) for c in range(16, 24) for s in (1, 2, 4, 8, 16, 32)]
+        for cfg, sk in variants:
+            if sk > 1 and (K // sk < 128 or sk * max(M, 128) * N * 4 > ws.numel()):
+                continue
+            def run(W):
+                return lib.paella_op_gemm(A.data_ptr(), W.data_ptr(), None, None, C.data_ptr(), M, N, K, 0, cfg, sk, ws.data_ptr(), ws.numel(), st())
+            if run(Ws[0]) != 0:
+                continue
+            ts = []
+            for _ in range(max(3, a.iters // 6)):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for W in Ws:
+                    run(W)
+                e1.record()
+                e1.synchronize()
+                ts.append(e0.elapsed_time(e1) * 1e3 / ncopy)
+            ts.sort()
+            us = ts[len(ts) // 2]
+            row["%d/%d" % (cfg, sk)] = round(us, 2)
+        flops = 2.0 * M * N * K
+        best = min((v, k) for k, v in row.items() if not k.startswith("-1"))
+        heur = row.get("-1/1")
+        results[name] = {"MNK": [M, N, K], "us": row, "best": best[1], "best_us": best[0], "best_tflops": round(flops / best[0] / 1e6, 1),
+                         "heuristic_us": heur, "heuristic_tflops": round(flops / heur / 1e6, 1) if heur else None,
+                         "hbm_floor_us": round((M * K + N * K + M * N) * 4 / 6.3e6, 2), "mfma_floor_us": round(flops / 157.3e6, 2)}
+        r = results[name]
+        print("%-28s best %-6s %8.1f us %6.1f TF | heuristic %8.1f us %6.1f TF | floors hbm %.1f mfma %.1f us" %
+              (name, r["best"], r["best_us"], r["best_tflops"], heur, r["heuristic_tflops"], r["hbm_floor_us"], r["mfma_floor_us"]), flush=True)
+    if a.out:
+        os.makedirs(os.path.dirname(a.out), exist_ok=True)
+        json.dump(results, open(a.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
