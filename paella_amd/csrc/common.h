@@ -107,6 +107,9 @@ int launch_dwconv_res(const float* x, const float* xt, const float* w, const flo
 int launch_grn_scale(const float* g, const float* gamma, float* scale, float* tmp_gx, int B,
                      int rows_per_sample, int C, hipStream_t stream);
 
+// same statistics from the GEMM epilogue's per-16-row partials (Epilogue::sumsq_out): part [B*groups, C]
+int launch_grn_from_partials(const float* part, const float* gamma, float* scale, int B, int groups, int C, hipStream_t stream);
+
 // Token embedding gather + LayerNorm(c_in) + PixelUnshuffle(p): tokens int64 [B,H,W] ->
 // out [B*(H/p)*(W/p), c_in*p*p] with channel index c*p*p + dy*p + dx.
 int launch_embed_ln_unshuffle(const int64_t* tokens, const float* table, float* out, int B, int H, int W,

@@ -165,8 +165,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void dwconv_ln_kernel(const f
     }
 }
 
-int launch_dwconv_ln(const float* x, const float* skip, const float* w, const float* bias, float* y, int B, int H,
-                     int W, int C, float eps, hipStream_t st) {
+// (superseded on the per-step path by the workgroup-per-position kernel in dwconv.hip; kept as the
+//  large-batch / bandwidth-bound variant and as a cross-check in the tests)
+int launch_dwconv_ln_onewave(const float* x, const float* skip, const float* w, const float* bias, float* y, int B, int H,
+                             int W, int C, float eps, hipStream_t st) {
     const int64_t total = (int64_t)B * H * W;
     if (total <= 0) return PAELLA_OK;
     if ((C & 3) || (skip && (C & 7))) { paella_set_error("dwconv_ln: bad channel count %d", C); return PAELLA_ERR_ARG; }
@@ -280,6 +282,51 @@ __global__ __launch_bounds__(256) void grn_finalize_kernel(const float* __restri
     }
     const float denom = red[0] / (float)C + 1e-6f;
     for (int c = threadIdx.x; c < C; c += 256) scale[(size_t)b * C + c] = 1.0f + gamma[c] * (p[c] / denom);
+}
+
+// GRN statistics from the per-16-row column sums of squares the GEMM epilogue already produced
+// (Epilogue::sumsq_out): one workgroup per sample sums the sample's row groups in fixed order, takes the channel
+// mean and writes scale[b][c] = 1 + gamma[c] * Gx / (mean + 1e-6).  Replaces the two-pass kernels above on the
+// per-step path (no re-read of the 4c-wide hidden tensor).
+__global__ __launch_bounds__(256) void grn_from_partials_kernel(const float* __restrict__ part, const float* __restrict__ gamma,
+                                                                float* __restrict__ scale, int groups, int C) {
+    // grid (ceil(C/1024), B): every workgroup recomputes the sample's channel mean (tiny, L2-resident, identical
+    // fixed-order arithmetic in every workgroup -> deterministic) and then writes the scale of its own 1024 channels.
+    __shared__ float red[256];
+    const int b = blockIdx.y;
+    const int C4 = C >> 2;
+    const float* p = part + (size_t)b * groups * C;
+    float s = 0.f;
+    for (int c4 = threadIdx.x; c4 < C4; c4 += 256) {
+        f32x4 q = ld4(p + c4 * 4);
+        for (int g = 1; g < groups; ++g) q += ld4(p + (size_t)g * C + c4 * 4);
+        s += (sqrtf(q[0]) + sqrtf(q[1])) + (sqrtf(q[2]) + sqrtf(q[3]));
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    const float denom = red[0] / (float)C + 1e-6f;
+    const int c4 = blockIdx.x * 256 + threadIdx.x;
+    if (c4 < C4) {
+        f32x4 q = ld4(p + c4 * 4);
+        for (int g = 1; g < groups; ++g) q += ld4(p + (size_t)g * C + c4 * 4);
+        const f32x4 gm = ld4(gamma + c4 * 4);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = 1.0f + gm[e] * (sqrtf(q[e]) / denom);
+        st4(scale + (size_t)b * C + c4 * 4, o);
+    }
+}
+
+int launch_grn_from_partials(const float* part, const float* gamma, float* scale, int B, int groups, int C, hipStream_t st) {
+    if (B <= 0) return PAELLA_OK;
+    if (C & 3) { paella_set_error("grn: C %% 4 != 0"); return PAELLA_ERR_ARG; }
+    hipLaunchKernelGGL(grn_from_partials_kernel, dim3((C / 4 + 255) / 256, B), dim3(256), 0, st, part, gamma, scale, groups, C);
+    LAUNCH_CHECK_RET();
+    return PAELLA_OK;
 }
 
 int launch_grn_scale(const float* g, const float* gamma, float* scale, float* tmp_gx, int B, int rows_per_sample,

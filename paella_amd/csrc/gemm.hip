@@ -21,9 +21,11 @@
 #include <stdio.h>
 #include <vector>
 
+#define RET_IF_G(expr) do { int _rc = (expr); if (_rc != PAELLA_OK) return _rc; } while (0)
+
 template <int WM, int WN, int TM, int TN, bool APRO>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g, int kslice, float* __restrict__ partial,
-                                                      int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g, int kslice, int S, float* __restrict__ slabs,
+                                                      unsigned* __restrict__ counters, int tiles_m, int tiles_n) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16, BK = 32;
     constexpr int LA = (BM * 8 + 255) / 256, LB = (BN * 8 + 255) / 256;
     static_assert(WM * WN == 4, "4 waves per workgroup");
@@ -141,37 +143,98 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g, int kslice, fl
         __syncthreads();
     }
 
+    // ---- split-K: write this slice's fp32 slab in fragment order (fully coalesced); splitk_reduce_frag_kernel sums the
+    // slabs in fixed slice order and runs the epilogue.  (An in-launch "last arriver" combine was measured 1.7x SLOWER
+    // end to end here: every workgroup pays an agent-scope release fence of several us -- see DESIGN.md.) ----
+    if (S > 1) {
+        constexpr int FR = TM * TN * 64 * 4;  // floats per wave, fragment order [i][j][lane][4]
+        float* my = slabs + ((size_t)bid * S + blockIdx.y) * (4 * FR) + (size_t)wave * FR;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) *reinterpret_cast<f32x4*>(my + ((i * TN + j) * 64 + lane) * 4) = acc[i][j];
+        return;
+    }
+
     // ---- epilogue: lane holds out[m = ..+r16][n = ..+kq*4 .. +3] ----
-    const bool split = (partial != nullptr);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + (wm * TM + i) * 16 + r16;
-        if (m >= g.M) continue;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + (wn * TN + j) * 16 + kq * 4;
-            if (n >= g.N) continue;
-            if (split) {
-                *reinterpret_cast<f32x4*>(partial + ((size_t)blockIdx.y * g.M + m) * g.N + n) = acc[i][j];
-            } else {
-                epilogue_store(g.ep, g.C, g.ldc, g.N, m, n, acc[i][j]);
+            const bool ok = m < g.M && n < g.N;
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (ok) {
+                v = epilogue_apply(g.ep, g.N, m, n, acc[i][j]);
+                epilogue_write(g.ep, g.C, g.ldc, m, n, v);
+            }
+            if (g.ep.sumsq_out) {  // kernel-uniform: per-16-row column sums of squares (GlobalResponseNorm statistics)
+                f32x4 q = v * v;
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    q[0] += __shfl_xor(q[0], o, 64);
+                    q[1] += __shfl_xor(q[1], o, 64);
+                    q[2] += __shfl_xor(q[2], o, 64);
+                    q[3] += __shfl_xor(q[3], o, 64);
+                }
+                const int mg = m0 + (wm * TM + i) * 16;
+                if (r16 == 0 && n < g.N && mg < g.M) *reinterpret_cast<f32x4*>(g.ep.sumsq_out + (size_t)(mg >> 4) * g.N + n) = q;
             }
         }
     }
 }
 
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int S, int M, int N,
-                                                            float* __restrict__ C, int ldc, Epilogue ep) {
-    const int n4 = N >> 2;
-    const size_t total = (size_t)M * n4;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (size_t)gridDim.x * blockDim.x) {
-        const int m = (int)(idx / n4);
-        const int n = (int)(idx - (size_t)m * n4) << 2;
-        const float* p = partial + (size_t)m * N + n;
-        f32x4 v = *reinterpret_cast<const f32x4*>(p);
-        for (int s = 1; s < S; ++s) v += *reinterpret_cast<const f32x4*>(p + (size_t)s * M * N);
-        epilogue_store(ep, C, ldc, N, m, n, v);
+// Split-K reducer: one workgroup per output tile, same thread -> element mapping as gemm_nt_kernel, so every slab
+// load is a coalesced 1 KiB wave access and the epilogue (incl. the GRN column sums of squares) is shared code.
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(256) void splitk_reduce_frag_kernel(GemmArgs g, int S, const float* __restrict__ slabs,
+                                                                 int tiles_m, int tiles_n) {
+    constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+    constexpr int FR = TM * TN * 64 * 4;
+    const int bid = blockIdx.x;  // already the remapped tile id used by the producer
+    const int tile_m = bid % tiles_m, tile_n = bid / tiles_m;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const float* base = slabs + (size_t)bid * S * (4 * FR) + (size_t)wave * FR;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + (wm * TM + i) * 16 + r16;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const float* p = base + ((i * TN + j) * 64 + lane) * 4;
+            f32x4 acc = *reinterpret_cast<const f32x4*>(p);
+            int s = 1;
+            for (; s + 3 < S; s += 4) {  // 4 loads in flight, added in slice order
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(p + (size_t)(s + 0) * (4 * FR));
+                const f32x4 a1 = *reinterpret_cast<const f32x4*>(p + (size_t)(s + 1) * (4 * FR));
+                const f32x4 a2 = *reinterpret_cast<const f32x4*>(p + (size_t)(s + 2) * (4 * FR));
+                const f32x4 a3 = *reinterpret_cast<const f32x4*>(p + (size_t)(s + 3) * (4 * FR));
+                acc += a0; acc += a1; acc += a2; acc += a3;
+            }
+            for (; s < S; ++s) acc += *reinterpret_cast<const f32x4*>(p + (size_t)s * (4 * FR));
+            const int n = n0 + (wn * TN + j) * 16 + kq * 4;
+            const bool ok = m < g.M && n < g.N;
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (ok) {
+                v = epilogue_apply(g.ep, g.N, m, n, acc);
+                epilogue_write(g.ep, g.C, g.ldc, m, n, v);
+            }
+            if (g.ep.sumsq_out) {
+                f32x4 q = v * v;
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    q[0] += __shfl_xor(q[0], o, 64);
+                    q[1] += __shfl_xor(q[1], o, 64);
+                    q[2] += __shfl_xor(q[2], o, 64);
+                    q[3] += __shfl_xor(q[3], o, 64);
+                }
+                const int mg = m0 + (wm * TM + i) * 16;
+                if (r16 == 0 && n < g.N && mg < g.M) *reinterpret_cast<f32x4*>(g.ep.sumsq_out + (size_t)(mg >> 4) * g.N + n) = q;
+            }
+        }
     }
 }
 
@@ -193,15 +256,30 @@ static const TileCfg kCfgs[] = {
 static const int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
 template <int WM, int WN, int TM, int TN>
-static void launch_one(const GemmArgs& g, int kslice, int S, float* partial, hipStream_t st) {
+static void launch_one(const GemmArgs& g, int kslice, int S, float* slabs, unsigned* counters, hipStream_t st) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
     const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
     dim3 grid(tiles_m * tiles_n, S);
     if (g.a_scale)
-        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, true>), grid, dim3(256), 0, st, g, kslice, partial, tiles_m, tiles_n);
+        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, true>), grid, dim3(256), 0, st, g, kslice, S, slabs, counters, tiles_m, tiles_n);
     else
-        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, false>), grid, dim3(256), 0, st, g, kslice, partial, tiles_m, tiles_n);
+        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, false>), grid, dim3(256), 0, st, g, kslice, S, slabs, counters, tiles_m, tiles_n);
+    if (S > 1)
+        hipLaunchKernelGGL((splitk_reduce_frag_kernel<WM, WN, TM, TN>), dim3(tiles_m * tiles_n), dim3(256), 0, st, g, S, slabs, tiles_m, tiles_n);
 }
+
+// ticket counters for the in-launch split-K reduction: zero at allocation, re-armed by each tile's last arriver
+static unsigned* g_counters = nullptr;
+static const int kMaxTiles = 1 << 16;
+int gemm_tile_counters(unsigned** out) {
+    if (!g_counters) {
+        HIP_CHECK_RET(hipMalloc((void**)&g_counters, kMaxTiles * sizeof(unsigned)));
+        HIP_CHECK_RET(hipMemset(g_counters, 0, kMaxTiles * sizeof(unsigned)));
+    }
+    *out = g_counters;
+    return PAELLA_OK;
+}
+int gemm_max_tiles() { return kMaxTiles; }
 
 size_t gemm_splitk_ws_bytes(int M, int N, int K) {
     (void)K;
@@ -223,7 +301,7 @@ static void choose_config(int M, int N, int K, size_t ws_bytes, int* cfg_out, in
         const long tiles = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
         for (int S = 1; S <= 16; S *= 2) {
             const int ks = ((K + S - 1) / S + 31) / 32 * 32;
-            if (S > 1 && (ks < 160 || (size_t)S * M * N * 4 > ws_bytes)) break;
+            if (S > 1 && (ks < 160 || (size_t)S * tiles * BM * BN * 4 > ws_bytes || tiles > kMaxTiles)) break;
             const int Seff = (K + ks - 1) / ks;
             const long wgs = tiles * Seff;
             double fill = wgs >= 768 ? 1.0 : (double)wgs / 768.0;
@@ -311,39 +389,33 @@ static int launch_gemm_cfg_impl(const GemmArgs& g, int cfg, int splitk, void* ws
     int S = splitk;
     if (cfg < 0) choose_config(g.M, g.N, g.K, ws ? ws_bytes : 0, &cfg, &S);
     if (cfg >= 16 && cfg < 24) return launch_gemm_ws(g, (cfg - 16) >> 1, ((cfg - 16) & 1) + 1, S, ws, ws_bytes, st);
-    if (g.ep.sumsq_out) { paella_set_error("gemm: sumsq epilogue needs a weight-streaming config"); return PAELLA_ERR_ARG; }
     if (cfg >= kNumCfgs) { paella_set_error("gemm: bad tile config %d", cfg); return PAELLA_ERR_ARG; }
     if (S < 1) S = 1;
     int kslice = ((g.K + S - 1) / S + 31) / 32 * 32;
     S = (g.K + kslice - 1) / kslice;
     if (S < 1) S = 1;
-    float* partial = nullptr;
+    unsigned* counters = nullptr;  // (only the weight-streaming variant still combines in-launch)
     if (S > 1) {
-        if ((size_t)S * g.M * g.N * sizeof(float) > ws_bytes || !ws) {
+        const int BM = kCfgs[cfg].wm * kCfgs[cfg].tm * 16, BN = kCfgs[cfg].wn * kCfgs[cfg].tn * 16;
+        const size_t tiles = (size_t)((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+        if (!ws || tiles * S * BM * BN * sizeof(float) > ws_bytes || tiles > (size_t)kMaxTiles) {
             paella_set_error("gemm: split-K workspace too small");
             return PAELLA_ERR_WORKSPACE;
         }
-        partial = reinterpret_cast<float*>(ws);
     }
+    float* slabs = reinterpret_cast<float*>(ws);
     switch (cfg) {
-        case 0: launch_one<2, 2, 4, 4>(g, kslice, S, partial, st); break;
-        case 1: launch_one<2, 2, 4, 2>(g, kslice, S, partial, st); break;
-        case 2: launch_one<2, 2, 2, 2>(g, kslice, S, partial, st); break;
-        case 3: launch_one<2, 2, 2, 1>(g, kslice, S, partial, st); break;
-        case 4: launch_one<2, 2, 1, 2>(g, kslice, S, partial, st); break;
-        case 5: launch_one<2, 2, 1, 1>(g, kslice, S, partial, st); break;
-        case 6: launch_one<1, 4, 1, 1>(g, kslice, S, partial, st); break;
-        case 7: launch_one<1, 4, 1, 2>(g, kslice, S, partial, st); break;
-        case 8: launch_one<1, 4, 2, 2>(g, kslice, S, partial, st); break;
+        case 0: launch_one<2, 2, 4, 4>(g, kslice, S, slabs, counters, st); break;
+        case 1: launch_one<2, 2, 4, 2>(g, kslice, S, slabs, counters, st); break;
+        case 2: launch_one<2, 2, 2, 2>(g, kslice, S, slabs, counters, st); break;
+        case 3: launch_one<2, 2, 2, 1>(g, kslice, S, slabs, counters, st); break;
+        case 4: launch_one<2, 2, 1, 2>(g, kslice, S, slabs, counters, st); break;
+        case 5: launch_one<2, 2, 1, 1>(g, kslice, S, slabs, counters, st); break;
+        case 6: launch_one<1, 4, 1, 1>(g, kslice, S, slabs, counters, st); break;
+        case 7: launch_one<1, 4, 1, 2>(g, kslice, S, slabs, counters, st); break;
+        case 8: launch_one<1, 4, 2, 2>(g, kslice, S, slabs, counters, st); break;
     }
     LAUNCH_CHECK_RET();
-    if (S > 1) {
-        const size_t total = (size_t)g.M * (g.N >> 2);
-        int blocks = (int)((total + 255) / 256);
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, partial, S, g.M, g.N, g.C, g.ldc, g.ep);
-        LAUNCH_CHECK_RET();
-    }
     return PAELLA_OK;
 }
 

@@ -215,11 +215,11 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(GemmArgs g, int kslice, in
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
-static unsigned* g_counters = nullptr;
-static const int kMaxTiles = 1 << 16;
+int gemm_tile_counters(unsigned** out);  // gemm.hip
+int gemm_max_tiles();
 
 template <int TM, int TN, int BK>
-static void launch_ws(const GemmArgs& g, int kslice, int S, float* slabs, int tiles_m, int tiles_n, hipStream_t st) {
+static void launch_ws(const GemmArgs& g, int kslice, int S, float* slabs, unsigned* g_counters, int tiles_m, int tiles_n, hipStream_t st) {
     dim3 grid(tiles_m * tiles_n, S);
     if (g.a_scale)
         hipLaunchKernelGGL((gemm_ws_kernel<TM, TN, BK, true>), grid, dim3(256), 0, st, g, kslice, S, slabs, g_counters, tiles_m, tiles_n);
@@ -229,10 +229,9 @@ static void launch_ws(const GemmArgs& g, int kslice, int S, float* slabs, int ti
 
 // tm_code: 0..3 -> TM = 1,2,4,8 ; tn in {1,2}
 int launch_gemm_ws(const GemmArgs& g, int tm_code, int tn, int splitk, void* ws, size_t ws_bytes, hipStream_t st) {
-    if (!g_counters) {
-        HIP_CHECK_RET(hipMalloc((void**)&g_counters, kMaxTiles * sizeof(unsigned)));
-        HIP_CHECK_RET(hipMemset(g_counters, 0, kMaxTiles * sizeof(unsigned)));
-    }
+    unsigned* g_counters = nullptr;
+    { const int rc = gemm_tile_counters(&g_counters); if (rc != PAELLA_OK) return rc; }
+    const int kMaxTiles = gemm_max_tiles();
     const int TM = 1 << tm_code, BM = 16 * TM, BN = 64 * tn;
     const int BK = TM >= 8 ? 32 : (TM == 4 ? 64 : 128);
     const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
@@ -247,7 +246,7 @@ int launch_gemm_ws(const GemmArgs& g, int tm_code, int tn, int splitk, void* ws,
         }
     }
     float* slabs = reinterpret_cast<float*>(ws);
-#define WS_CASE(TMv, TNv, BKv) launch_ws<TMv, TNv, BKv>(g, kslice, S, slabs, tiles_m, tiles_n, st)
+#define WS_CASE(TMv, TNv, BKv) launch_ws<TMv, TNv, BKv>(g, kslice, S, slabs, g_counters, tiles_m, tiles_n, st)
     if (tn == 1) {
         switch (tm_code) {
             case 0: WS_CASE(1, 1, 128); break;

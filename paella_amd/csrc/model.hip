@@ -401,7 +401,10 @@ static void carve_forward(const paella_unet* m, Arena& a, int B, int H, int W, i
     f.h = a.take(hmax);
     f.g = a.take(gmax);
     f.grn_scale = a.take((size_t)B * 4 * m->c_max);
-    f.grn_gx = a.take((size_t)B * 4 * m->c_max);
+    {   // also holds the GEMM epilogue's per-16-row sum-of-squares partials: [rows/16, 4c] <= gmax/16
+        const size_t a1 = (size_t)B * 4 * m->c_max, a2 = gmax / 16 + 64;
+        f.grn_gx = a.take(a1 > a2 ? a1 : a2);
+    }
     f.ts = a.take((size_t)B * (m->ts_total > 0 ? m->ts_total : 1));
     f.remb = a.take((size_t)B * c.c_r);
     f.splitk = a.take(kSplitKBudget / sizeof(float));
@@ -541,8 +544,15 @@ static int run_mlp_block(FwdCtx& cx, const Block& b, float* x, const float* skip
     GemmArgs g1 = gemm_args(cx.f.h, ch, T(m, b.prefix + ".channelwise.0.weight"), ch, cx.f.g, 4 * ch, (int)rows, 4 * ch, ch);
     g1.ep.bias = T(m, b.prefix + ".channelwise.0.bias");
     g1.ep.act = ACT_GELU;
-    RET_IF(launch_gemm(g1, cx.f.splitk, kSplitKBudget, cx.st));
-    RET_IF(launch_grn_scale(cx.f.g, T(m, b.prefix + ".channelwise.2.gamma"), cx.f.grn_scale, cx.f.grn_gx, cx.B, rps, 4 * ch, cx.st));
+    if (rps % 16 == 0) {
+        // GRN statistics ride on GEMM1's epilogue (per-16-row column sums of squares), then one tiny finalize launch
+        g1.ep.sumsq_out = cx.f.grn_gx;
+        RET_IF(launch_gemm(g1, cx.f.splitk, kSplitKBudget, cx.st));
+        RET_IF(launch_grn_from_partials(cx.f.grn_gx, T(m, b.prefix + ".channelwise.2.gamma"), cx.f.grn_scale, cx.B, rps / 16, 4 * ch, cx.st));
+    } else {
+        RET_IF(launch_gemm(g1, cx.f.splitk, kSplitKBudget, cx.st));
+        RET_IF(launch_grn_scale(cx.f.g, T(m, b.prefix + ".channelwise.2.gamma"), cx.f.grn_scale, cx.f.grn_gx, cx.B, rps, 4 * ch, cx.st));
+    }
     GemmArgs g2 = gemm_args(cx.f.g, 4 * ch, T(m, b.prefix + ".channelwise.4.weight"), 4 * ch, x, ch, (int)rows, ch, 4 * ch);
     g2.a_scale = cx.f.grn_scale;
     g2.a_shift = T(m, b.prefix + ".channelwise.2.beta");
