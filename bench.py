@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--grid", type=int, default=32, help="token grid side (32 = 256 px at f8)")
     ap.add_argument("--sample-steps", type=int, default=8)
     ap.add_argument("--noise", default="philox", choices=["philox", "torch"])
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one captured HIP graph per image batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the informational batched-throughput run")
     ap.add_argument("--extra-batch", type=int, default=8)
@@ -142,6 +143,14 @@ def main():
         uncond_all = synth.synth_conditioning(total, 0, mcfg["byt5_embd"], mcfg["clip_embd"], seed=3, device=device)
     lo, hi = shard_bounds(total, rank, world)
     counter = [0]
+    use_graph = not a.no_graph and a.noise == "philox"
+    sampler = None
+    if use_graph:
+        # capture sample() + decode once for this rank's shapes; every step replays it with fresh conditioning / seed
+        c0 = synth.synth_conditioning(a.batch, 0, mcfg["byt5_embd"], mcfg["clip_embd"], seed=2, device=device)
+        u0 = synth.synth_conditioning(a.batch, 0, mcfg["byt5_embd"], mcfg["clip_embd"], seed=3, device=device)
+        sampler = paella_amd.GraphSampler(model, c0, u0, (a.batch, a.grid, a.grid), steps=a.sample_steps, renoise_steps=a.sample_steps - 1,
+                                          temperature=(1.0, 0.2), cfg=8.0, device=device, vqgan=vq)
 
     def step():
         if distributed:
@@ -150,6 +159,13 @@ def main():
         else:
             c, u = cond_all, uncond_all
         counter[0] += 1
+        if sampler is not None:
+            return sampler(c, u, seed=1000 * counter[0] + rank)[1]
+        return gen_images(model, vq, c, u, a.batch, a.grid, a.sample_steps, a.noise, 1000 * counter[0] + rank, device)
+
+    def step_eager():
+        counter[0] += 1
+        c, u = (cond_all, uncond_all) if not distributed else (shard_inputs(cond_all, lo, hi), shard_inputs(uncond_all, lo, hi))
         return gen_images(model, vq, c, u, a.batch, a.grid, a.sample_steps, a.noise, 1000 * counter[0] + rank, device)
 
     dt = timed(step, a.steps, a.warmup, distributed, device)
@@ -158,11 +174,11 @@ def main():
     ms_per_step = dt / a.steps * 1e3
 
     # ---- roofline of the dominant kernel family (fp32 MFMA GEMM): one extra identical pass with every GEMM launch
-    # bracketed by HIP events on its stream (the timed region above runs without the events)
+    # bracketed by HIP events on its stream (eager launches; the timed region above runs without the events)
     roof = None
     if rank == 0:
         lib.paella_prof_enable(1)
-        step()
+        step_eager()
         torch.cuda.synchronize(device)
         ms, fl, by, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
         lib.paella_prof_collect(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by), ctypes.byref(n))
@@ -184,7 +200,12 @@ def main():
         eb = a.extra_batch
         ce = synth.synth_conditioning(eb, 0, mcfg["byt5_embd"], mcfg["clip_embd"], seed=2, device=device)
         ue = synth.synth_conditioning(eb, 0, mcfg["byt5_embd"], mcfg["clip_embd"], seed=3, device=device)
-        fn = lambda: gen_images(model, vq, ce, ue, eb, a.grid, a.sample_steps, a.noise, 77, device)
+        if use_graph:
+            gs = paella_amd.GraphSampler(model, ce, ue, (eb, a.grid, a.grid), steps=a.sample_steps, renoise_steps=a.sample_steps - 1,
+                                         temperature=(1.0, 0.2), cfg=8.0, device=device, vqgan=vq)
+            fn = lambda: gs(ce, ue, seed=77)
+        else:
+            fn = lambda: gen_images(model, vq, ce, ue, eb, a.grid, a.sample_steps, a.noise, 77, device)
         k = max(2, a.steps // 3)
         dte = timed(fn, k, 1, False, device)
         extra = {"batch": eb, "images_per_sec": round(eb * k / dte, 3), "ms_per_image": round(dte / (eb * k) * 1e3, 3)}
@@ -207,7 +228,7 @@ def main():
                                    "%d steps, CFG 8.0, CLIP-H-text only (S=4), batch %d per GPU, + VQGAN f8 decode"
                                    % (n_params / 1e6, a.grid, a.grid, a.grid * 8, a.sample_steps, a.batch),
                        "model": a.model, "batch_per_gpu": a.batch, "global_batch": total, "grid": a.grid, "sample_steps": a.sample_steps,
-                       "noise": a.noise, "parallelism": "batch-shard x%d, one conditioning broadcast per step" % world},
+                       "noise": a.noise, "submission": "hip-graph replay" if use_graph else "eager launches", "parallelism": "batch-shard x%d, one conditioning broadcast per step" % world},
             "roofline": roof, "cpu_baseline": cpu, "batched": extra,
         }
         print(json.dumps(line), flush=True)

@@ -118,6 +118,13 @@ int paella_sample_tail(const float* logits_c, const float* logits_u, int64_t row
                        uint64_t offset, const int64_t* init_noise, const float* mask_u, float t_next,
                        int64_t* tokens_out, int64_t* sampled_out, void* stream);
 
+/* Same, with an optional DEVICE-resident seed word added to `seed` (seed_ptr may be NULL): a HIP graph that captured
+ * the sampling loop can then be replayed with fresh noise by rewriting that one word. */
+int paella_sample_tail_ex(const float* logits_c, const float* logits_u, int64_t rows, int L, float cfg,
+                          float one_minus_cfg, float temperature, int mode, const float* noise_q, uint64_t seed,
+                          const uint64_t* seed_ptr, uint64_t offset, const int64_t* init_noise, const float* mask_u,
+                          float t_next, int64_t* tokens_out, int64_t* sampled_out, void* stream);
+
 /* x, random_x, mask int64 [B, per_sample]; t fp32 [B].  mask_in NULL -> mask = (u <= t[b]) with u = rand_u
  * (caller noise, [B, per_sample]) or Philox; random_x NULL -> Philox randint(0, num_labels). */
 int paella_add_noise(const int64_t* x, const float* t, const int64_t* mask_in, const int64_t* random_x,
@@ -178,6 +185,10 @@ int paella_op_attention(const float* q, const float* k_self, const float* v_self
  * ---------------------------------------------------------------------------------------------- */
 int paella_prof_enable(int on);
 int paella_prof_collect(double* total_ms, double* total_flops, double* total_bytes, int64_t* launches);
+/* launches n_launches dependent, nearly empty kernels (blocks x 256 threads touching n_elems floats): boundary floor */
+int paella_debug_launch_chain(float* buf, int n_elems, int blocks, int n_launches, void* stream);
+/* A/B switch for the GEMM workgroup-spreading LDS reservation (default on) */
+int paella_debug_set_spread(int on);
 
 #ifdef __cplusplus
 }

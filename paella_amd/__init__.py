@@ -9,8 +9,8 @@ Public surface (mirrors the reference's Python API):
 Everything executes through libpaella_hip.so (hand-written HIP for gfx950, C ABI in include/paella_hip.h).
 """
 from .modules import CondCache, DenoiseUNet, Paella, replace_attention_layers
-from .sampling import sample, sample_distributed
+from .sampling import GraphSampler, sample, sample_distributed
 from .vqgan import VectorQuantize, VQModel
 
-__all__ = ["Paella", "DenoiseUNet", "CondCache", "VQModel", "VectorQuantize", "sample", "sample_distributed",
+__all__ = ["Paella", "DenoiseUNet", "CondCache", "VQModel", "VectorQuantize", "sample", "sample_distributed", "GraphSampler",
            "replace_attention_layers"]

@@ -54,6 +54,8 @@ SIGNATURES = {
                                     c_void_p, c_void_p, c_size_t, c_void_p]),
     "paella_sample_tail": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, c_float, c_float, c_int, c_void_p,
                                    c_uint64, c_uint64, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
+    "paella_sample_tail_ex": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, c_float, c_float, c_int, c_void_p,
+                                      c_uint64, c_void_p, c_uint64, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
     "paella_add_noise": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint64, c_uint64, c_int, c_int,
                                  c_int64, c_void_p, c_void_p, c_void_p]),
     "paella_vqgan_create": (c_int, [POINTER(VqganConfig), POINTER(c_void_p)]),
@@ -68,6 +70,8 @@ SIGNATURES = {
     "paella_vqgan_quantize_rows": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "paella_prof_enable": (c_int, [c_int]),
     "paella_prof_collect": (c_int, [POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int64)]),
+    "paella_debug_set_spread": (c_int, [c_int]),
+    "paella_debug_launch_chain": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     "paella_op_gemm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                c_void_p, c_size_t, c_void_p]),
     "paella_op_layernorm": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]),

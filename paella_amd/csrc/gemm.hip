@@ -23,9 +23,9 @@
 
 #define RET_IF_G(expr) do { int _rc = (expr); if (_rc != PAELLA_OK) return _rc; } while (0)
 
-template <int WM, int WN, int TM, int TN, bool APRO>
+template <int WM, int WN, int TM, int TN, int PD, bool APRO>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g, int kslice, int S, float* __restrict__ slabs,
-                                                      unsigned* __restrict__ counters, int tiles_m, int tiles_n) {
+                                                      int tiles_m, int tiles_n) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16, BK = 32;
     constexpr int LA = (BM * 8 + 255) / 256, LB = (BN * 8 + 255) / 256;
     static_assert(WM * WN == 4, "4 waves per workgroup");
@@ -58,11 +58,14 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g, int kslice, in
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // Loads are unconditional from clamped in-bounds addresses and never select-masked in the steady state (a load
-    // under a lane condition, or a select on its result inside a conditional block, makes hipcc wait for it at once).
-    // Out-of-range rows only feed outputs that are never stored; the K tail is zeroed on the ACTIVATION side only.
-    f32x4 ra[LA], rb[LB], rs[APRO ? LA : 1], rt;
-    rt = f32x4{0.f, 0.f, 0.f, 0.f};
+    // Global -> register ring -> LDS.  The ring holds PD K-tiles in flight per workgroup: with split-K the K loop of a
+    // workgroup is only 5-10 tiles long and HBM latency (~2k cycles loaded) is several tile-times, so a 1-deep
+    // prefetch leaves the matrix cores waiting.  Loads are unconditional from clamped in-bounds addresses and never
+    // select-masked (a load under a lane condition, or a select on its result inside a conditional block, makes hipcc
+    // wait for it at once); out-of-range rows only feed outputs that are never stored, and the K tail is zeroed on the
+    // ACTIVATION side only when the tile is written to LDS.
+    struct Stage { f32x4 a[LA]; f32x4 s[APRO ? LA : 1]; f32x4 t; f32x4 b[LB]; };
+    Stage R[PD];
     const float* aptr[LA];
     const float* sptr[APRO ? LA : 1];
     const float* bptr[LB];
@@ -75,73 +78,106 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g, int kslice, in
 #pragma unroll
     for (int i = 0; i < LB; ++i) bptr[i] = g.W + (size_t)min(n0 + ldrow + i * 32, g.N - 1) * g.ldw;
 
-    auto load_tile = [&](int k0) {
-        const int kc = min(k0 + ldc4 * 4, g.K - 4);
+    auto load_tile = [&](Stage& r, int t) {
+        const int kc = min(kbeg + t * BK + ldc4 * 4, g.K - 4);
 #pragma unroll
         for (int i = 0; i < LA; ++i) {
-            ra[i] = *reinterpret_cast<const f32x4*>(aptr[i] + kc);
-            if (APRO) rs[i] = *reinterpret_cast<const f32x4*>(sptr[i] + kc);
+            r.a[i] = *reinterpret_cast<const f32x4*>(aptr[i] + kc);
+            if (APRO) r.s[i] = *reinterpret_cast<const f32x4*>(sptr[i] + kc);
         }
-        if (APRO) rt = *reinterpret_cast<const f32x4*>(g.a_shift + kc);
+        if (APRO) r.t = *reinterpret_cast<const f32x4*>(g.a_shift + kc);
 #pragma unroll
-        for (int i = 0; i < LB; ++i) rb[i] = *reinterpret_cast<const f32x4*>(bptr[i] + kc);
+        for (int i = 0; i < LB; ++i) r.b[i] = *reinterpret_cast<const f32x4*>(bptr[i] + kc);
     };
-    auto store_tile = [&](int buf, int k0) {
-        float* As = smem + buf * (BM + BN) * BK;
+    auto store_tile = [&](const Stage& r, int t) {
+        float* As = smem + (t & 1) * (BM + BN) * BK;
         float* Bs = As + BM * BK;
-        const bool kok = k0 + ldc4 * 4 < kend;
+        const bool kok = kbeg + t * BK + ldc4 * 4 < kend;
 #pragma unroll
         for (int i = 0; i < LA; ++i) {
             const int row = ldrow + i * 32;
-            f32x4 v = ra[i];
-            if (APRO) v = v * rs[i] + rt;
+            f32x4 v = r.a[i];
+            if (APRO) v = v * r.s[i] + r.t;
             if (!kok) v = f32x4{0.f, 0.f, 0.f, 0.f};
             if (LA * 32 == BM || row < BM) *reinterpret_cast<f32x4*>(As + row * BK + ((ldc4 ^ (row & 7)) << 2)) = v;
         }
 #pragma unroll
         for (int i = 0; i < LB; ++i) {
             const int row = ldrow + i * 32;
-            if (LB * 32 == BN || row < BN) *reinterpret_cast<f32x4*>(Bs + row * BK + ((ldc4 ^ (row & 7)) << 2)) = rb[i];
+            if (LB * 32 == BN || row < BN) *reinterpret_cast<f32x4*>(Bs + row * BK + ((ldc4 ^ (row & 7)) << 2)) = r.b[i];
         }
     };
-
-    const int ntiles = (kend - kbeg + BK - 1) / BK;
-    load_tile(kbeg);
-    store_tile(0, kbeg);
-    __syncthreads();
-
-    for (int t = 0; t < ntiles; ++t) {
-        const int buf = t & 1;
-        load_tile(kbeg + (t + 1) * BK);
-        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch above the MFMA block (hipcc sinks it otherwise)
-        const float* As = smem + buf * (BM + BN) * BK;
+    // All fragment reads of the tile are issued up front (one exposed LDS latency per tile, not one per 16-k group),
+    // and a 1x1 wave tile alternates two accumulators so its MFMAs are never back-to-back dependent
+    // (v_mfma_f32_16x16x4_f32: 32-cycle issue, 40-cycle dependent latency).
+    constexpr bool DUAL = (TM * TN == 1);
+    f32x4 acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](int t) {
+        const float* As = smem + (t & 1) * (BM + BN) * BK;
         const float* Bs = As + BM * BK;
+        f32x4 af[2][TM], bf[2][TN];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            f32x4 af[TM], bf[TN];
             const int c4 = kk * 4 + kq;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int row = (wm * TM + i) * 16 + r16;
-                af[i] = *reinterpret_cast<const f32x4*>(As + row * BK + ((c4 ^ (row & 7)) << 2));
+                af[kk][i] = *reinterpret_cast<const f32x4*>(As + row * BK + ((c4 ^ (row & 7)) << 2));
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int row = (wn * TN + j) * 16 + r16;
-                bf[j] = *reinterpret_cast<const f32x4*>(Bs + row * BK + ((c4 ^ (row & 7)) << 2));
+                bf[kk][j] = *reinterpret_cast<const f32x4*>(Bs + row * BK + ((c4 ^ (row & 7)) << 2));
             }
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][e], af[i][e], acc[i][j], 0, 0, 0);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        store_tile(buf ^ 1, kbeg + (t + 1) * BK);
-        __syncthreads();
+        if (DUAL) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[0][0][e], af[0][0][e], acc[0][0], 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[1][0][e], af[1][0][e], acc2, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[kk][j][e], af[kk][i][e], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    const int ntiles = (kend - kbeg + BK - 1) / BK;
+    // invariant at the top of iteration t: tile t is in LDS[t&1]; R[(t+1)%PD .. (t+PD-1)%PD] hold tiles t+1..t+PD-1; R[t%PD] is free
+#pragma unroll
+    for (int j = 0; j < PD; ++j) load_tile(R[j], j);
+    store_tile(R[0], 0);
+    __syncthreads();
+    int t = 0;
+    for (; t + PD <= ntiles; t += PD) {  // full chunks: no per-tile conditionals, one basic block per tile
+#pragma unroll
+        for (int u = 0; u < PD; ++u) {
+            load_tile(R[u], t + u + PD);
+            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch above the MFMA block (hipcc sinks it otherwise)
+            compute(t + u);
+            __builtin_amdgcn_sched_barrier(0);
+            store_tile(R[(u + 1) % PD], t + u + 1);
+            __syncthreads();
+        }
     }
+    const int rem = ntiles - t;  // < PD tiles left: tile t is in LDS, t+1.. are in R[1..]
+#pragma unroll
+    for (int u = 0; u < PD - 1; ++u) {
+        if (u < rem) {
+            compute(t + u);
+            if (u + 1 < rem) store_tile(R[(u + 1) % PD], t + u + 1);
+            __syncthreads();
+        }
+    }
+
+    if (DUAL) acc[0][0] += acc2;
 
     // ---- split-K: write this slice's fp32 slab in fragment order (fully coalesced); splitk_reduce_frag_kernel sums the
     // slabs in fixed slice order and runs the epilogue.  (An in-launch "last arriver" combine was measured 1.7x SLOWER
@@ -255,20 +291,38 @@ static const TileCfg kCfgs[] = {
 };
 static const int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
-template <int WM, int WN, int TM, int TN>
-static void launch_one(const GemmArgs& g, int kslice, int S, float* slabs, unsigned* counters, hipStream_t st) {
+// Workgroup spreading: the hardware dispatcher packs workgroups onto a CU up to its occupancy limit before moving on,
+// so a 640-workgroup grid of small tiles lands on ~1/3 of the 256 CUs (measured: SQ_BUSY_CU_CYCLES = 64 % of the
+// kernel, every tile config ~26 us where the matrix-core floor is 11 us).  Reserving unused dynamic LDS caps the
+// workgroups per CU at ceil(grid / 256) so a sub-capacity grid spreads over the whole chip.
+static int g_spread = 1;
+extern "C" int paella_debug_set_spread(int on) { g_spread = on; return PAELLA_OK; }
+
+template <int WM, int WN, int TM, int TN, int PD>
+static void launch_one(const GemmArgs& g, int kslice, int S, float* slabs, hipStream_t st) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+    constexpr int kStaticLds = 2 * (BM + BN) * 32 * 4;
     const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
     dim3 grid(tiles_m * tiles_n, S);
+    const long wgs = (long)tiles_m * tiles_n * S;
+    size_t pad = 0;
+    if (g_spread) {
+        const long per_cu = (wgs + 255) / 256;
+        if (per_cu < 8) {
+            const size_t want = (size_t)(160 * 1024) / (size_t)per_cu - 512;  // LDS per workgroup that admits exactly per_cu of them
+            if (want > (size_t)kStaticLds) pad = (want - kStaticLds) & ~(size_t)255;
+            if (kStaticLds + pad > 64 * 1024) pad = 64 * 1024 - kStaticLds;   // stay within the default 64 KiB launch limit
+        }
+    }
     if (g.a_scale)
-        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, true>), grid, dim3(256), 0, st, g, kslice, S, slabs, counters, tiles_m, tiles_n);
+        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, PD, true>), grid, dim3(256), pad, st, g, kslice, S, slabs, tiles_m, tiles_n);
     else
-        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, false>), grid, dim3(256), 0, st, g, kslice, S, slabs, counters, tiles_m, tiles_n);
+        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, PD, false>), grid, dim3(256), pad, st, g, kslice, S, slabs, tiles_m, tiles_n);
     if (S > 1)
         hipLaunchKernelGGL((splitk_reduce_frag_kernel<WM, WN, TM, TN>), dim3(tiles_m * tiles_n), dim3(256), 0, st, g, S, slabs, tiles_m, tiles_n);
 }
 
-// ticket counters for the in-launch split-K reduction: zero at allocation, re-armed by each tile's last arriver
+// ticket counters for the weight-streaming variant's in-launch split-K reduction (gemm_ws.hip)
 static unsigned* g_counters = nullptr;
 static const int kMaxTiles = 1 << 16;
 int gemm_tile_counters(unsigned** out) {
@@ -286,33 +340,41 @@ size_t gemm_splitk_ws_bytes(int M, int N, int K) {
     return (size_t)16 * M * N * sizeof(float);  // up to 16 slabs
 }
 
-// Tile / split-K choice.  Fitted to tools/gemm_tune.py sweeps on MI355X (gpurun_out/gemm_tune*.json): every variant
-// behaves like  t = fixed + flops / (157 TF * tile_eff * occupancy_fill) + slab traffic, with fixed ~4 us for one launch
-// and ~8 us when a split-K reduce launch follows; small tiles + enough workgroups (~5 per CU) win for skinny M.
+// Tile / split-K choice, fitted to tools/gemm_tune.py sweeps on MI355X (profiles/r01_gemm_tile_split_sweep*.txt).
+// What the sweeps show: a lone workgroup needs ~0.35 us per K-tile with 32x32 tiles (~0.73 us with 64x64) no matter
+// how idle the chip is (load -> LDS -> barrier -> MFMA chain), so skinny problems want SHORT K loops (10-20 tiles per
+// workgroup, via split-K) and at least ~320 workgroups; once >= ~1000 workgroups exist the 64x64 tile is the most
+// efficient (85-90 % of the matrix-core rate at the sustained clock) and splitting only costs slab traffic.
 static void choose_config(int M, int N, int K, size_t ws_bytes, int* cfg_out, int* split_out) {
-    static const int cand[] = {1, 2, 4, 3, 5};
-    static const double eff[] = {0.72, 0.70, 0.66, 0.66, 0.62};
-    const double flops_us = 2.0 * M * N * K / 157.3e6;
-    double best = 1e30;
-    int bc = 5, bs = 1;
-    for (int ci = 0; ci < 5; ++ci) {
-        const int c = cand[ci];
+    auto tiles_of = [&](int c) {
         const int BM = kCfgs[c].wm * kCfgs[c].tm * 16, BN = kCfgs[c].wn * kCfgs[c].tn * 16;
-        const long tiles = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-        for (int S = 1; S <= 16; S *= 2) {
-            const int ks = ((K + S - 1) / S + 31) / 32 * 32;
-            if (S > 1 && (ks < 160 || (size_t)S * tiles * BM * BN * 4 > ws_bytes || tiles > kMaxTiles)) break;
-            const int Seff = (K + ks - 1) / ks;
-            const long wgs = tiles * Seff;
-            double fill = wgs >= 768 ? 1.0 : (double)wgs / 768.0;
-            if (wgs > 1280) fill *= (double)wgs / (double)(((wgs + 1279) / 1280) * 1280);
-            double t = (Seff > 1 ? 8.0 : 4.0) + flops_us / (eff[ci] * fill);
-            if (Seff > 1) t += (double)Seff * M * N * 8.0 / 8.0e6;
-            if (t < best) { best = t; bc = c; bs = Seff; }
+        return (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    };
+    const int ktiles = (K + 31) / 32;
+    int cfg, S = 1;
+    if (tiles_of(0) >= 1024 && K <= 512) {
+        cfg = 0;
+    } else if (tiles_of(2) >= 256) {  // large M: 64x64 tiles, split only to reach ~1280 workgroups
+        cfg = 2;
+        const long t = tiles_of(2);
+        while (t * S < 1024 && S < 16 && ktiles / (S * 2) >= 5) S *= 2;
+    } else {                          // skinny: 32x32 tiles, K loop of 10-20 tiles, >= 320 workgroups
+        cfg = 5;
+        const long t = tiles_of(5);
+        if (t < 1024) {
+            while (ktiles / S > 20 && S < 16) S *= 2;
+            while (t * S < 320 && S < 16 && ktiles / (S * 2) >= 5) S *= 2;
+            while (S > 1 && t * S > 2560) S /= 2;
         }
     }
-    *cfg_out = bc;
-    *split_out = bs;
+    // workspace / tile-count limits
+    for (;;) {
+        const int BM = kCfgs[cfg].wm * kCfgs[cfg].tm * 16, BN = kCfgs[cfg].wn * kCfgs[cfg].tn * 16;
+        if (S == 1 || ((size_t)S * tiles_of(cfg) * BM * BN * 4 <= ws_bytes && tiles_of(cfg) <= kMaxTiles)) break;
+        S /= 2;
+    }
+    *cfg_out = cfg;
+    *split_out = S;
 }
 
 // ---------------------------------------------------------------------------
@@ -389,12 +451,13 @@ static int launch_gemm_cfg_impl(const GemmArgs& g, int cfg, int splitk, void* ws
     int S = splitk;
     if (cfg < 0) choose_config(g.M, g.N, g.K, ws ? ws_bytes : 0, &cfg, &S);
     if (cfg >= 16 && cfg < 24) return launch_gemm_ws(g, (cfg - 16) >> 1, ((cfg - 16) & 1) + 1, S, ws, ws_bytes, st);
+    const bool pd1 = cfg >= 32;
+    if (pd1) cfg -= 32;
     if (cfg >= kNumCfgs) { paella_set_error("gemm: bad tile config %d", cfg); return PAELLA_ERR_ARG; }
     if (S < 1) S = 1;
     int kslice = ((g.K + S - 1) / S + 31) / 32 * 32;
     S = (g.K + kslice - 1) / kslice;
     if (S < 1) S = 1;
-    unsigned* counters = nullptr;  // (only the weight-streaming variant still combines in-launch)
     if (S > 1) {
         const int BM = kCfgs[cfg].wm * kCfgs[cfg].tm * 16, BN = kCfgs[cfg].wn * kCfgs[cfg].tn * 16;
         const size_t tiles = (size_t)((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
@@ -404,16 +467,26 @@ static int launch_gemm_cfg_impl(const GemmArgs& g, int cfg, int splitk, void* ws
         }
     }
     float* slabs = reinterpret_cast<float*>(ws);
-    switch (cfg) {
-        case 0: launch_one<2, 2, 4, 4>(g, kslice, S, slabs, counters, st); break;
-        case 1: launch_one<2, 2, 4, 2>(g, kslice, S, slabs, counters, st); break;
-        case 2: launch_one<2, 2, 2, 2>(g, kslice, S, slabs, counters, st); break;
-        case 3: launch_one<2, 2, 2, 1>(g, kslice, S, slabs, counters, st); break;
-        case 4: launch_one<2, 2, 1, 2>(g, kslice, S, slabs, counters, st); break;
-        case 5: launch_one<2, 2, 1, 1>(g, kslice, S, slabs, counters, st); break;
-        case 6: launch_one<1, 4, 1, 1>(g, kslice, S, slabs, counters, st); break;
-        case 7: launch_one<1, 4, 1, 2>(g, kslice, S, slabs, counters, st); break;
-        case 8: launch_one<1, 4, 2, 2>(g, kslice, S, slabs, counters, st); break;
+    // prefetch depth per tile config: as deep as ~32-48 staging VGPRs allow
+    if (!pd1) {
+        switch (cfg) {
+            case 0: launch_one<2, 2, 4, 4, 1>(g, kslice, S, slabs, st); break;
+            case 1: launch_one<2, 2, 4, 2, 2>(g, kslice, S, slabs, st); break;
+            case 2: launch_one<2, 2, 2, 2, 2>(g, kslice, S, slabs, st); break;
+            case 3: launch_one<2, 2, 2, 1, 2>(g, kslice, S, slabs, st); break;
+            case 4: launch_one<2, 2, 1, 2, 2>(g, kslice, S, slabs, st); break;
+            case 5: launch_one<2, 2, 1, 1, 2>(g, kslice, S, slabs, st); break;
+            case 6: launch_one<1, 4, 1, 1, 2>(g, kslice, S, slabs, st); break;
+            case 7: launch_one<1, 4, 1, 2, 2>(g, kslice, S, slabs, st); break;
+            case 8: launch_one<1, 4, 2, 2, 2>(g, kslice, S, slabs, st); break;
+        }
+    } else {  // 1-deep prefetch variants kept for A/B measurements (tools/gemm_tune.py, cfg + 32)
+        switch (cfg) {
+            case 2: launch_one<2, 2, 2, 2, 1>(g, kslice, S, slabs, st); break;
+            case 4: launch_one<2, 2, 1, 2, 1>(g, kslice, S, slabs, st); break;
+            case 5: launch_one<2, 2, 1, 1, 1>(g, kslice, S, slabs, st); break;
+            default: paella_set_error("gemm: no PD=1 variant for tile config %d", cfg); return PAELLA_ERR_ARG;
+        }
     }
     LAUNCH_CHECK_RET();
     return PAELLA_OK;

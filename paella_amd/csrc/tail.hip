@@ -55,6 +55,7 @@ __global__ __launch_bounds__(256) void sample_tail_kernel(TailArgs a) {
     const float* lu = a.logits_u ? a.logits_u + row * L : nullptr;
     const bool has_u = lu != nullptr;
     const bool argmax_mode = a.mode == 1;
+    const uint64_t seed = a.seed + (a.seed_ptr ? *a.seed_ptr : 0ull);
 
     // pass 1: max of x = mix / T
     float mx = -INFINITY;
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(256) void sample_tail_kernel(TailArgs a) {
                 q = *reinterpret_cast<const f32x4*>(nq + i4 * 4);
             } else {
                 uint32_t rb[4];
-                philox4x32(a.seed, (uint64_t)row * L4 + i4, a.offset, rb);
+                philox4x32(seed, (uint64_t)row * L4 + i4, a.offset, rb);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) q[e] = -logf(u01_open(rb[e]));
             }
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(256) void sample_tail_kernel(TailArgs a) {
                 u = a.mask_u[row];
             } else {
                 uint32_t rb[4];
-                philox4x32(a.seed ^ 0x5bd1e9955bd1e995ull, (uint64_t)row, a.offset, rb);
+                philox4x32(seed ^ 0x5bd1e9955bd1e995ull, (uint64_t)row, a.offset, rb);
                 u = u01_half_open(rb[0]);
             }
             if (u <= a.t_next) tok = a.init_noise[row];
@@ -177,6 +178,19 @@ int launch_add_noise(const int64_t* x, const float* t, const int64_t* mask_in, c
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(add_noise_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, t, mask_in, random_x, rand_u, seed,
                        offset, num_labels, total, per_sample, x_out, mask_out);
+    LAUNCH_CHECK_RET();
+    return PAELLA_OK;
+}
+
+// ---------------------------------------------------------------------------
+// measurement hook: a chain of n dependent, nearly empty kernels on `stream` (launch-boundary floor of this box)
+// ---------------------------------------------------------------------------
+__global__ void chain_kernel(float* p, int bytes4) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < bytes4) p[i] += 1.0f;
+}
+extern "C" int paella_debug_launch_chain(float* buf, int n_elems, int blocks, int n_launches, void* stream) {
+    for (int i = 0; i < n_launches; ++i) hipLaunchKernelGGL(chain_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, buf, n_elems);
     LAUNCH_CHECK_RET();
     return PAELLA_OK;
 }

@@ -60,18 +60,20 @@ def _cat_inputs(a, b):
     return out
 
 
-def _tail(logits_c, logits_u, rows, L, cfg, omc, temperature, mode, noise_q, seed, offset, init_noise, mask_u, t_next, out):
+def _tail(logits_c, logits_u, rows, L, cfg, omc, temperature, mode, noise_q, seed, offset, init_noise, mask_u, t_next, out,
+          seed_dev=None):
     lib = _lib.load()
     dev = logits_c.device
     with torch.cuda.device(dev):
-        _lib.check(lib.paella_sample_tail(_lib.ptr(logits_c), _lib.ptr(logits_u), rows, L, cfg, omc, temperature, mode,
-                                          _lib.ptr(noise_q), seed, offset, _lib.ptr(init_noise), _lib.ptr(mask_u), t_next,
-                                          _lib.ptr(out), None, _lib.stream_ptr(dev)))
+        _lib.check(lib.paella_sample_tail_ex(_lib.ptr(logits_c), _lib.ptr(logits_u), rows, L, cfg, omc, temperature, mode,
+                                             _lib.ptr(noise_q), seed, _lib.ptr(seed_dev), offset, _lib.ptr(init_noise),
+                                             _lib.ptr(mask_u), t_next, _lib.ptr(out), None, _lib.stream_ptr(dev)))
 
 
 def _sample_core(model, model_inputs, unconditional_inputs, latent_shape, init_x, steps, renoise_steps, t_list, temperatures,
-                 cfgs, device, noise="torch", seed=0, attn_weights=None):
-    """cfgs: per-step list of (cfg_fp32, one_minus_cfg_fp32) or None (no guidance at that step)."""
+                 cfgs, device, noise="torch", seed=0, attn_weights=None, seed_dev=None, init_noise_buf=None):
+    """cfgs: per-step list of (cfg_fp32, one_minus_cfg_fp32) or None (no guidance at that step).
+    seed_dev / init_noise_buf: device-resident seed word and pre-drawn start tokens (HIP-graph capture, see GraphSampler)."""
     explicit = isinstance(noise, dict)  # parity tests: {"init_noise": [B,H,W], "q": [rows,L] per step, "u": [B,H,W] per step}
     if not explicit and noise not in ("torch", "philox"):
         raise ValueError("noise must be 'torch', 'philox' or a dict of explicit noise tensors")
@@ -84,7 +86,9 @@ def _sample_core(model, model_inputs, unconditional_inputs, latent_shape, init_x
     rows = B * H * W
     native = isinstance(model, Paella)
     with torch.inference_mode():
-        if explicit:
+        if init_noise_buf is not None:
+            init_noise = init_noise_buf
+        elif explicit:
             init_noise = noise["init_noise"].to(device=device, dtype=torch.int64).contiguous()
         else:
             init_noise = torch.randint(0, L, size=(B, H, W), device=device)
@@ -140,7 +144,7 @@ def _sample_core(model, model_inputs, unconditional_inputs, latent_shape, init_x
                 mask_u = torch.rand(B, H, W, dtype=torch.float32, device=device)  # == torch.rand_like(x.float())
             cfg, omc = cfgs[i] if use_cfg else (1.0, 0.0)
             _tail(lc, lu, rows, L, cfg, omc, temp if mode == 0 else 1.0, mode, noise_q, seed, i,
-                  init_noise if renoise else None, mask_u, t_list[i + 1] if renoise else 0.0, out)
+                  init_noise if renoise else None, mask_u, t_list[i + 1] if renoise else 0.0, out, seed_dev=seed_dev)
             sampled = out  # the tail never reads `sampled`, so one output buffer is enough (stream-ordered reuse)
     return sampled
 
@@ -182,3 +186,82 @@ def sample_distributed(model, model_inputs, unconditional_inputs, latent_shape, 
             cfgs[i] = (float(sched[i]), float(1 - sched[i]))
     return _sample_core(model, model_inputs, unconditional_inputs, latent_shape, init_x, steps, renoise_steps, t_list, temperatures,
                         cfgs, device, noise=noise, seed=seed, attn_weights=attn_weights)
+
+
+class GraphSampler:
+    """The whole `sample()` call (conditioning prep, all denoising steps, sampling tails; optionally the VQGAN
+    decode) captured ONCE into a HIP graph for fixed shapes and replayed per request.
+
+    Why: at batch 1 the path is ~3000 short kernels per image and eager launches are host-bound at ~2.8 us per kernel
+    on this platform (tools/launch_floor.py), a graph replays the same kernels at ~1.6-1.8 us.  Arithmetic, kernels and
+    results are identical to `sample(..., noise="philox")`; only the submission mechanism changes.  Per request the
+    conditioning tensors are copied into the graph's static input buffers, fresh start tokens are drawn with
+    torch.randint (as the reference does) and the Philox seed word in device memory is rewritten.
+    """
+
+    def __init__(self, model, model_inputs, unconditional_inputs, latent_shape, steps=12, renoise_steps=11, temperature=(1.0, 0.2),
+                 cfg=8.0, t_start=1.0, t_end=0.0, device="cuda", vqgan=None, attn_weights=None):
+        self.model, self.vqgan, self.device = model, vqgan, torch.device(device)
+        self.shape = tuple(int(v) for v in latent_shape)
+        self.kw = dict(steps=steps, renoise_steps=renoise_steps, temperature=temperature, cfg=cfg, t_start=t_start, t_end=t_end)
+        self.attn_weights = attn_weights
+        clone = lambda d: None if d is None else {k: (None if v is None else ([t.clone() for t in v] if isinstance(v, (list, tuple)) else v.clone()))
+                                                  for k, v in d.items()}
+        self.cond, self.uncond = clone(model_inputs), clone(unconditional_inputs)
+        self.seed_dev = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self.init_noise = torch.zeros(self.shape, dtype=torch.int64, device=self.device)
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            for _ in range(2):  # warm-up: weights loaded, workspaces sized, allocator pools populated
+                self._run()
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = self._run()
+        torch.cuda.synchronize(self.device)
+
+    def _run(self):
+        k = self.kw
+        t_list = linspace_schedule(k["t_start"], k["t_end"], k["steps"] + 1)
+        temps = linspace_schedule(k["temperature"][0], k["temperature"][1], k["steps"])
+        if k["cfg"]:
+            pair = (float(torch.tensor(float(k["cfg"]), dtype=torch.float32)), float(torch.tensor(1.0 - float(k["cfg"]), dtype=torch.float32)))
+            cfgs = [pair] * k["steps"]
+        else:
+            cfgs = [None] * k["steps"]
+        toks = _sample_core(self.model, self.cond, self.uncond, self.shape, None, k["steps"], k["renoise_steps"], t_list, temps, cfgs,
+                            self.device, noise="philox", seed=0, attn_weights=self.attn_weights, seed_dev=self.seed_dev,
+                            init_noise_buf=self.init_noise)
+        return toks if self.vqgan is None else (toks, self.vqgan.decode_indices(toks))
+
+    @staticmethod
+    def _copy_inputs(dst, src):
+        if dst is None:
+            return
+        for key, d in dst.items():
+            s = src.get(key) if src is not None else None
+            if d is None:
+                if s is not None:
+                    raise ValueError("conditioning layout differs from the captured one (%s)" % key)
+                continue
+            if isinstance(d, (list, tuple)):
+                for a, b in zip(d, s):
+                    a.copy_(b)
+            else:
+                if s is None or s.shape != d.shape:
+                    raise ValueError("conditioning shape differs from the captured one (%s)" % key)
+                d.copy_(s)
+
+    def __call__(self, model_inputs=None, unconditional_inputs=None, seed=0):
+        """Replay. Returns tokens (and the decoded image if a VQGAN was given); outputs live in graph-owned buffers that
+        the next replay overwrites."""
+        if model_inputs is not None:
+            self._copy_inputs(self.cond, model_inputs)
+        if unconditional_inputs is not None:
+            self._copy_inputs(self.uncond, unconditional_inputs)
+        torch.randint(0, self.model.num_labels, self.shape, device=self.device, out=self.init_noise)
+        self.seed_dev.fill_(int(seed))
+        self.graph.replay()
+        return self.out

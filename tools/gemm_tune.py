@@ -47,7 +47,7 @@ def main():
         Ws = [torch.randn(N, K, device="cuda") for _ in range(ncopy)]
         C = torch.empty(M, N, device="cuda")
         row = {}
-        variants = [(-1, 1)] + [(c, s) for c in range(9) for s in (1, 2, 4, 8, 16)] + [(c, s) for c in range(16, 24) for s in (1, 2, 4, 8, 16, 32)]
+        variants = [(-1, 1)] + [(c, s) for c in range(9) for s in (1, 2, 4, 8, 16)] + [(c, s) for c in (34, 36, 37) for s in (1, 2, 4, 8, 16)]
         for cfg, sk in variants:
             if sk > 1 and (K // sk < 128 or sk * max(M, 128) * N * 4 > ws.numel()):
                 continue
@@ -69,13 +69,14 @@ def main():
             row["%d/%d" % (cfg, sk)] = round(us, 2)
         flops = 2.0 * M * N * K
         best = min((v, k) for k, v in row.items() if not k.startswith("-1"))
+        pd1 = min([(v, k) for k, v in row.items() if int(k.split('/')[0]) >= 32] or [(0, '-')])
         heur = row.get("-1/1")
         results[name] = {"MNK": [M, N, K], "us": row, "best": best[1], "best_us": best[0], "best_tflops": round(flops / best[0] / 1e6, 1),
                          "heuristic_us": heur, "heuristic_tflops": round(flops / heur / 1e6, 1) if heur else None,
                          "hbm_floor_us": round((M * K + N * K + M * N) * 4 / 6.3e6, 2), "mfma_floor_us": round(flops / 157.3e6, 2)}
         r = results[name]
-        print("%-28s best %-6s %8.1f us %6.1f TF | heuristic %8.1f us %6.1f TF | floors hbm %.1f mfma %.1f us" %
-              (name, r["best"], r["best_us"], r["best_tflops"], heur, r["heuristic_tflops"], r["hbm_floor_us"], r["mfma_floor_us"]), flush=True)
+        print("%-28s best %-6s %8.1f us %6.1f TF | heuristic %8.1f us %6.1f TF | best PD=1 %-6s %6.1f us | floors hbm %.1f mfma %.1f us" %
+              (name, r["best"], r["best_us"], r["best_tflops"], heur, r["heuristic_tflops"], pd1[1], pd1[0], r["hbm_floor_us"], r["mfma_floor_us"]), flush=True)
     if a.out:
         os.makedirs(os.path.dirname(a.out), exist_ok=True)
         json.dump(results, open(a.out, "w"), indent=1)
