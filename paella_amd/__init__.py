@@ -8,9 +8,10 @@ Public surface (mirrors the reference's Python API):
     replace_attention_layers  reference utils/alter_attention.py:45
 Everything executes through libpaella_hip.so (hand-written HIP for gfx950, C ABI in include/paella_hip.h).
 """
+from .editing import inpaint
 from .modules import CondCache, DenoiseUNet, Paella, replace_attention_layers
 from .sampling import GraphSampler, sample, sample_distributed
 from .vqgan import VectorQuantize, VQModel
 
 __all__ = ["Paella", "DenoiseUNet", "CondCache", "VQModel", "VectorQuantize", "sample", "sample_distributed", "GraphSampler",
-           "replace_attention_layers"]
+           "replace_attention_layers", "inpaint"]

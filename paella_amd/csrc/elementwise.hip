@@ -288,18 +288,35 @@ __global__ __launch_bounds__(256) void grn_finalize_kernel(const float* __restri
 // (Epilogue::sumsq_out): one workgroup per sample sums the sample's row groups in fixed order, takes the channel
 // mean and writes scale[b][c] = 1 + gamma[c] * Gx / (mean + 1e-6).  Replaces the two-pass kernels above on the
 // per-step path (no re-read of the 4c-wide hidden tensor).
+template <int G>  // G > 0: compile-time group count (all loads of a channel quad in flight together); 0 = runtime
 __global__ __launch_bounds__(256) void grn_from_partials_kernel(const float* __restrict__ part, const float* __restrict__ gamma,
-                                                                float* __restrict__ scale, int groups, int C) {
+                                                                float* __restrict__ scale, int groups_rt, int C) {
     // grid (ceil(C/1024), B): every workgroup recomputes the sample's channel mean (tiny, L2-resident, identical
     // fixed-order arithmetic in every workgroup -> deterministic) and then writes the scale of its own 1024 channels.
     __shared__ float red[256];
+    const int groups = G > 0 ? G : groups_rt;
     const int b = blockIdx.y;
     const int C4 = C >> 2;
     const float* p = part + (size_t)b * groups * C;
+    auto colsum = [&](int c4) {
+        f32x4 q = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (G > 0) {
+            f32x4 v[G > 0 ? G : 1];
+#pragma unroll
+            for (int g = 0; g < G; ++g) v[g] = ld4(p + (size_t)g * C + c4 * 4);
+#pragma unroll
+            for (int g = 0; g < G; ++g) q += v[g];
+        } else {
+            for (int g = 0; g < groups; ++g) q += ld4(p + (size_t)g * C + c4 * 4);
+        }
+        return q;
+    };
     float s = 0.f;
+    f32x4 mine = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int my_c4 = blockIdx.x * 256 + threadIdx.x;
     for (int c4 = threadIdx.x; c4 < C4; c4 += 256) {
-        f32x4 q = ld4(p + c4 * 4);
-        for (int g = 1; g < groups; ++g) q += ld4(p + (size_t)g * C + c4 * 4);
+        const f32x4 q = colsum(c4);
+        if (c4 == my_c4) mine = q;
         s += (sqrtf(q[0]) + sqrtf(q[1])) + (sqrtf(q[2]) + sqrtf(q[3]));
     }
     red[threadIdx.x] = s;
@@ -309,22 +326,25 @@ __global__ __launch_bounds__(256) void grn_from_partials_kernel(const float* __r
         __syncthreads();
     }
     const float denom = red[0] / (float)C + 1e-6f;
-    const int c4 = blockIdx.x * 256 + threadIdx.x;
-    if (c4 < C4) {
-        f32x4 q = ld4(p + c4 * 4);
-        for (int g = 1; g < groups; ++g) q += ld4(p + (size_t)g * C + c4 * 4);
-        const f32x4 gm = ld4(gamma + c4 * 4);
+    if (my_c4 < C4) {
+        const f32x4 gm = ld4(gamma + my_c4 * 4);
         f32x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = 1.0f + gm[e] * (sqrtf(q[e]) / denom);
-        st4(scale + (size_t)b * C + c4 * 4, o);
+        for (int e = 0; e < 4; ++e) o[e] = 1.0f + gm[e] * (sqrtf(mine[e]) / denom);
+        st4(scale + (size_t)b * C + my_c4 * 4, o);
     }
 }
 
 int launch_grn_from_partials(const float* part, const float* gamma, float* scale, int B, int groups, int C, hipStream_t st) {
     if (B <= 0) return PAELLA_OK;
     if (C & 3) { paella_set_error("grn: C %% 4 != 0"); return PAELLA_ERR_ARG; }
-    hipLaunchKernelGGL(grn_from_partials_kernel, dim3((C / 4 + 255) / 256, B), dim3(256), 0, st, part, gamma, scale, groups, C);
+    const dim3 grid((C / 4 + 255) / 256, B), block(256);
+    switch (groups) {
+        case 1: hipLaunchKernelGGL((grn_from_partials_kernel<1>), grid, block, 0, st, part, gamma, scale, groups, C); break;
+        case 4: hipLaunchKernelGGL((grn_from_partials_kernel<4>), grid, block, 0, st, part, gamma, scale, groups, C); break;
+        case 16: hipLaunchKernelGGL((grn_from_partials_kernel<16>), grid, block, 0, st, part, gamma, scale, groups, C); break;
+        default: hipLaunchKernelGGL((grn_from_partials_kernel<0>), grid, block, 0, st, part, gamma, scale, groups, C); break;
+    }
     LAUNCH_CHECK_RET();
     return PAELLA_OK;
 }

@@ -23,7 +23,7 @@
 
 #define RET_IF_G(expr) do { int _rc = (expr); if (_rc != PAELLA_OK) return _rc; } while (0)
 
-template <int WM, int WN, int TM, int TN, int PD, bool APRO>
+template <int WM, int WN, int TM, int TN, int PD, bool APRO, bool GLDS>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g, int kslice, int S, float* __restrict__ slabs,
                                                       int tiles_m, int tiles_n) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16, BK = 32;
@@ -150,6 +150,36 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g, int kslice, in
     };
 
     const int ntiles = (kend - kbeg + BK - 1) / BK;
+    if constexpr (GLDS) {
+        // Direct global -> LDS DMA (global_load_lds_dwordx4): no VGPR staging and, above all, no ds_write_b128 (13 LDS-pipe
+        // cycles per wave-instruction -- for 32x32 tiles the LDS pipe, not the matrix cores, was the busiest unit).
+        // The LDS image of a wave's DMA is lane-linear (8 rows x 128 B), so the XOR swizzle is applied to the SOURCE
+        // chunk each lane fetches (guide rule 21); a row's 128-byte line is still fetched whole -> coalescing unchanged.
+        // Requires K % 32 == 0 (no tail masking), no A prologue, BM and BN multiples of 32 -- checked by the launcher.
+        const int swz = (tid & 7) ^ ((tid >> 3) & 7);
+        auto glds_tile = [&](int t) {
+            float* As = smem + (t & 1) * (BM + BN) * BK;
+            float* Bs = As + BM * BK;
+            const int kc = min(kbeg + t * BK, g.K - BK) + swz * 4;
+#pragma unroll
+            for (int i = 0; i < LA; ++i)
+                __builtin_amdgcn_global_load_lds((const void*)(aptr[i] + kc),
+                                                 (__attribute__((address_space(3))) void*)(As + (wave * 8 + i * 32) * BK), 16, 0, 0);
+#pragma unroll
+            for (int i = 0; i < LB; ++i)
+                __builtin_amdgcn_global_load_lds((const void*)(bptr[i] + kc),
+                                                 (__attribute__((address_space(3))) void*)(Bs + (wave * 8 + i * 32) * BK), 16, 0, 0);
+        };
+        glds_tile(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int t = 0; t < ntiles; ++t) {
+            glds_tile(t + 1);  // into the buffer every wave finished reading before the previous barrier
+            compute(t);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    } else {
     // invariant at the top of iteration t: tile t is in LDS[t&1]; R[(t+1)%PD .. (t+PD-1)%PD] hold tiles t+1..t+PD-1; R[t%PD] is free
 #pragma unroll
     for (int j = 0; j < PD; ++j) load_tile(R[j], j);
@@ -175,6 +205,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g, int kslice, in
             if (u + 1 < rem) store_tile(R[(u + 1) % PD], t + u + 1);
             __syncthreads();
         }
+    }
     }
 
     if (DUAL) acc[0][0] += acc2;
@@ -295,8 +326,10 @@ static const int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 // so a 640-workgroup grid of small tiles lands on ~1/3 of the 256 CUs (measured: SQ_BUSY_CU_CYCLES = 64 % of the
 // kernel, every tile config ~26 us where the matrix-core floor is 11 us).  Reserving unused dynamic LDS caps the
 // workgroups per CU at ceil(grid / 256) so a sub-capacity grid spreads over the whole chip.
-static int g_spread = 1;
-extern "C" int paella_debug_set_spread(int on) { g_spread = on; return PAELLA_OK; }
+static int g_spread = 0;
+static int g_glds = 0;  // measured neutral-to-negative on MI355X for these shapes (tools/gemm_warm_cold.py); kept for A/B
+// debug switches for A/B measurements: bit 0 = workgroup spreading (LDS reservation), bit 1 = direct global->LDS staging
+extern "C" int paella_debug_set_spread(int on) { g_spread = on & 1; g_glds = (on >> 1) & 1; return PAELLA_OK; }
 
 template <int WM, int WN, int TM, int TN, int PD>
 static void launch_one(const GemmArgs& g, int kslice, int S, float* slabs, hipStream_t st) {
@@ -314,10 +347,14 @@ static void launch_one(const GemmArgs& g, int kslice, int S, float* slabs, hipSt
             if (kStaticLds + pad > 64 * 1024) pad = 64 * 1024 - kStaticLds;   // stay within the default 64 KiB launch limit
         }
     }
+    constexpr bool kCanGlds = (BM % 32 == 0) && (BN % 32 == 0);
+    const bool glds = kCanGlds && g_glds && !g.a_scale && (g.K % 32 == 0) && g.K >= 32;
     if (g.a_scale)
-        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, PD, true>), grid, dim3(256), pad, st, g, kslice, S, slabs, tiles_m, tiles_n);
+        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, PD, true, false>), grid, dim3(256), pad, st, g, kslice, S, slabs, tiles_m, tiles_n);
+    else if (glds)
+        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, 1, false, kCanGlds>), grid, dim3(256), pad, st, g, kslice, S, slabs, tiles_m, tiles_n);
     else
-        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, PD, false>), grid, dim3(256), pad, st, g, kslice, S, slabs, tiles_m, tiles_n);
+        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, PD, false, false>), grid, dim3(256), pad, st, g, kslice, S, slabs, tiles_m, tiles_n);
     if (S > 1)
         hipLaunchKernelGGL((splitk_reduce_frag_kernel<WM, WN, TM, TN>), dim3(tiles_m * tiles_n), dim3(256), 0, st, g, S, slabs, tiles_m, tiles_n);
 }

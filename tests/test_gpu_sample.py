@@ -139,3 +139,27 @@ def test_graph_sampler_matches_eager(tiny, built_lib):
     torch.manual_seed(6)
     ref2 = paella_amd.sample(tiny, cs2, (2, 16, 16), unconditional_inputs=us, steps=4, renoise_steps=3, device=DEV, noise="philox", seed=10)
     assert torch.equal(t2, ref2) and not torch.equal(t2, toks)
+
+
+def test_inpaint_composition(tiny, built_lib):
+    """encode -> masked add_noise -> sample(init_x, t_start<1) -> decode (BASELINE config 5 path, small)."""
+    cfg = G.UNET_TINY
+    vc = dict(G.VQ_TINY_F8, codebook_size=cfg["num_labels"])
+    vq = paella_amd.VQModel(**vc)
+    weights_for(vq, 2)
+    vq = vq.to(DEV)
+    g = torch.Generator().manual_seed(4)
+    img = torch.rand(2, 3, 128, 128, generator=g).to(DEV)  # f8 -> 16x16 tokens
+    cs, us = to_dev(cond_for(cfg, 2, 3, 0, 1), DEV), to_dev(cond_for(cfg, 2, 3, 0, 2), DEV)
+    mask = torch.zeros(2, 16, 16, dtype=torch.int64)
+    mask[:, 4:12, 4:12] = 1
+    torch.manual_seed(1)
+    toks, out = paella_amd.inpaint(tiny, vq, img, mask, cs, us, steps=4, t_start=0.6)
+    orig = vq.encode(img)[2]
+    assert out.shape == img.shape and toks.shape == orig.shape
+    m = mask.to(DEV).bool()
+    assert torch.equal(toks[~m], orig[~m])          # known region preserved (keep_known extension)
+    assert (toks[m] != orig[m]).float().mean() > 0.2  # the hole was regenerated
+    # an all-zero mask is the identity on tokens
+    t0, _ = paella_amd.inpaint(tiny, vq, img, torch.zeros_like(mask), cs, us, steps=2, t_start=0.5, decode=False)
+    assert torch.equal(t0, orig)

@@ -152,3 +152,23 @@ def test_570m_forward_vs_oracle(built_lib):
     assert std > 0.05, "degenerate logits"
     assert diff <= 1e-3 * max(1.0, std)
     assert clear == 0
+
+
+def test_1b_forward_ragged_conditioning_vs_oracle(built_lib):
+    """Released-size model (default ctor, 1.007B params), ByT5 + CLIP text + CLIP image conditioning (S = 16), B = 2."""
+    cfg = G.UNET_1B
+    m = paella_amd.Paella(**cfg)
+    assert sum(p.numel() for p in m.parameters()) == 1007302016  # SURVEY D3
+    sd = weights_for(m, sum(cfg["blocks"]))
+    m = m.to(DEV)
+    g = torch.Generator().manual_seed(6)
+    x = torch.randint(0, 8192, (2, 16, 16), generator=g)
+    r = torch.tensor([0.9, 0.1])
+    c = cond_for(cfg, 2, 8, 1, G.COND_SEED)
+    with torch.no_grad():
+        ref = O.unet_forward(sd, cfg, x, r, **c)
+    got = m(x.to(DEV), r.to(DEV), **to_dev(c, DEV)).float().cpu()
+    diff = (got - ref).abs().max().item()
+    clear, near, n_near = argmax_report(ref, got)
+    print("1B forward: logit std %.3f, max|diff| %.3e, argmax mismatches clear=%d near-tie=%d" % (ref.std().item(), diff, clear, near))
+    assert diff <= 1e-3 * max(1.0, ref.std().item()) and clear == 0
