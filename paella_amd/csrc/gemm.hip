@@ -23,9 +23,11 @@
 
 #define RET_IF_G(expr) do { int _rc = (expr); if (_rc != PAELLA_OK) return _rc; } while (0)
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
 template <int WM, int WN, int TM, int TN, int PD, bool APRO, bool GLDS>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g, int kslice, int S, float* __restrict__ slabs,
-                                                      int tiles_m, int tiles_n) {
+                                                      int tiles_m, int tiles_n, unsigned* __restrict__ counters, unsigned slab_bytes) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16, BK = 32;
     constexpr int LA = (BM * 8 + 255) / 256, LB = (BN * 8 + 255) / 256;
     static_assert(WM * WN == 4, "4 waves per workgroup");
@@ -215,12 +217,51 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g, int kslice, in
     // end to end here: every workgroup pays an agent-scope release fence of several us -- see DESIGN.md.) ----
     if (S > 1) {
         constexpr int FR = TM * TN * 64 * 4;  // floats per wave, fragment order [i][j][lane][4]
-        float* my = slabs + ((size_t)bid * S + blockIdx.y) * (4 * FR) + (size_t)wave * FR;
+        if (!counters) {  // two-launch mode: splitk_reduce_frag_kernel combines
+            float* my = slabs + ((size_t)bid * S + blockIdx.y) * (4 * FR) + (size_t)wave * FR;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) *reinterpret_cast<f32x4*>(my + ((i * TN + j) * 64 + lane) * 4) = acc[i][j];
+            return;
+        }
+        // In-launch combine, write-through form (guide section 6 G16 recipe R1): slabs are stored with sc1 (agent-scope,
+        // write-through) so no release fence is needed; every storing wave drains vmcnt(0), ONE lane takes a relaxed
+        // agent-scope ticket; the last arriver reads all slabs back with sc1 loads (no acquire fence) in FIXED slice order.
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(slabs, 0, (int)slab_bytes, 0x00020000);
+        const unsigned mybase = (unsigned)((((size_t)bid * S + blockIdx.y) * (4 * FR) + (size_t)wave * FR) * sizeof(float));
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) *reinterpret_cast<f32x4*>(my + ((i * TN + j) * 64 + lane) * 4) = acc[i][j];
-        return;
+            for (int j = 0; j < TN; ++j)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rsrc,
+                                                       mybase + ((i * TN + j) * 64 + lane) * 16, 0, 16);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        unsigned* sflag = reinterpret_cast<unsigned*>(smem);
+        if (tid == 0) sflag[0] = __hip_atomic_fetch_add(counters + bid, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (sflag[0] != (unsigned)(S - 1)) return;
+        if (tid == 0) __hip_atomic_store(counters + bid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
+        const unsigned tbase = (unsigned)(((size_t)bid * S * (4 * FR) + (size_t)wave * FR) * sizeof(float));
+        const unsigned sstride = (unsigned)(4 * FR * sizeof(float));
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const unsigned off = tbase + ((i * TN + j) * 64 + lane) * 16;
+                f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 16));
+                int s = 1;
+                for (; s + 3 < S; s += 4) {
+                    const f32x4 a0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + (s + 0) * sstride, 0, 16));
+                    const f32x4 a1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + (s + 1) * sstride, 0, 16));
+                    const f32x4 a2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + (s + 2) * sstride, 0, 16));
+                    const f32x4 a3 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + (s + 3) * sstride, 0, 16));
+                    v += a0; v += a1; v += a2; v += a3;
+                }
+                for (; s < S; ++s) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + s * sstride, 0, 16));
+                acc[i][j] = v;
+            }
     }
 
     // ---- epilogue: lane holds out[m = ..+r16][n = ..+kq*4 .. +3] ----
@@ -327,9 +368,12 @@ static const int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 // kernel, every tile config ~26 us where the matrix-core floor is 11 us).  Reserving unused dynamic LDS caps the
 // workgroups per CU at ceil(grid / 256) so a sub-capacity grid spreads over the whole chip.
 static int g_spread = 0;
+int gemm_tile_counters(unsigned** out);
+static int g_combine = 1;  // in-launch split-K combine with write-through (sc1) slabs
 static int g_glds = 0;  // measured neutral-to-negative on MI355X for these shapes (tools/gemm_warm_cold.py); kept for A/B
 // debug switches for A/B measurements: bit 0 = workgroup spreading (LDS reservation), bit 1 = direct global->LDS staging
-extern "C" int paella_debug_set_spread(int on) { g_spread = on & 1; g_glds = (on >> 1) & 1; return PAELLA_OK; }
+// bit 2 (value 4) = DISABLE the in-launch split-K combine (use the two-launch reducer)
+extern "C" int paella_debug_set_spread(int on) { g_spread = on & 1; g_glds = (on >> 1) & 1; g_combine = ((on >> 2) & 1) ? 0 : 1; return PAELLA_OK; }
 
 template <int WM, int WN, int TM, int TN, int PD>
 static void launch_one(const GemmArgs& g, int kslice, int S, float* slabs, hipStream_t st) {
@@ -349,13 +393,16 @@ static void launch_one(const GemmArgs& g, int kslice, int S, float* slabs, hipSt
     }
     constexpr bool kCanGlds = (BM % 32 == 0) && (BN % 32 == 0);
     const bool glds = kCanGlds && g_glds && !g.a_scale && (g.K % 32 == 0) && g.K >= 32;
+    unsigned* counters = nullptr;
+    const size_t slab_bytes = (size_t)tiles_m * tiles_n * S * BM * BN * sizeof(float);
+    if (S > 1 && g_combine && slab_bytes < ((size_t)1 << 31)) (void)gemm_tile_counters(&counters);
     if (g.a_scale)
-        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, PD, true, false>), grid, dim3(256), pad, st, g, kslice, S, slabs, tiles_m, tiles_n);
+        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, PD, true, false>), grid, dim3(256), pad, st, g, kslice, S, slabs, tiles_m, tiles_n, counters, (unsigned)slab_bytes);
     else if (glds)
-        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, 1, false, kCanGlds>), grid, dim3(256), pad, st, g, kslice, S, slabs, tiles_m, tiles_n);
+        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, 1, false, kCanGlds>), grid, dim3(256), pad, st, g, kslice, S, slabs, tiles_m, tiles_n, counters, (unsigned)slab_bytes);
     else
-        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, PD, false, false>), grid, dim3(256), pad, st, g, kslice, S, slabs, tiles_m, tiles_n);
-    if (S > 1)
+        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, PD, false, false>), grid, dim3(256), pad, st, g, kslice, S, slabs, tiles_m, tiles_n, counters, (unsigned)slab_bytes);
+    if (S > 1 && !counters)
         hipLaunchKernelGGL((splitk_reduce_frag_kernel<WM, WN, TM, TN>), dim3(tiles_m * tiles_n), dim3(256), 0, st, g, S, slabs, tiles_m, tiles_n);
 }
 
