@@ -436,18 +436,19 @@ static void choose_config(int M, int N, int K, size_t ws_bytes, int* cfg_out, in
     };
     const int ktiles = (K + 31) / 32;
     int cfg, S = 1;
+    const double macs = (double)M * N * K;
     if (tiles_of(0) >= 1024 && K <= 512) {
         cfg = 0;
-    } else if (tiles_of(2) >= 256) {  // large M: 64x64 tiles, split only to reach ~1280 workgroups
+    } else if (tiles_of(2) >= 1024 || macs >= 3e9) {  // big problems: 64x64 tiles, split only to reach ~1024 workgroups
         cfg = 2;
         const long t = tiles_of(2);
         while (t * S < 1024 && S < 16 && ktiles / (S * 2) >= 5) S *= 2;
-    } else {                          // skinny: 32x32 tiles, K loop of 10-20 tiles, >= 320 workgroups
+    } else {                                          // skinny: 32x32 tiles, K loop <= 20 tiles, >= 512 workgroups
         cfg = 5;
         const long t = tiles_of(5);
         if (t < 1024) {
             while (ktiles / S > 20 && S < 16) S *= 2;
-            while (t * S < 320 && S < 16 && ktiles / (S * 2) >= 5) S *= 2;
+            while (t * S < 512 && S < 16 && ktiles / (S * 2) >= 5) S *= 2;
             while (S > 1 && t * S > 2560) S /= 2;
         }
     }
