@@ -184,9 +184,19 @@ def main():
         lib.paella_prof_collect(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by), ctypes.byref(n))
         lib.paella_prof_enable(0)
         ach = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+        # HBM traffic per launch from the committed PMC pass of this same workload (bench.py cannot collect PMC counters itself)
+        traffic, traffic_note = None, None
+        tp = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(tp):
+            tj = json.load(open(tp))
+            w = tj.get("workload", {})
+            if (w.get("model"), w.get("batch_per_gpu"), w.get("grid"), w.get("sample_steps")) == (a.model, a.batch, a.grid, a.sample_steps):
+                traffic = tj["hbm_bytes_per_launch"]
+                traffic_note = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/r01_pmc_traffic.json): 2*FETCH+WRITE KiB per launch, gfx950 correction applied"
         roof = {"bound": "mfma", "kernel": "gemm_nt_kernel (fp32 v_mfma_f32_16x16x4_f32, all tile configs, split-K reduce included)",
                 "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
-                "traffic": None, "launches_per_step": int(n.value), "avg_launch_us": round(ms.value * 1e3 / max(n.value, 1), 2),
+                "traffic": traffic, "traffic_source": traffic_note, "algorithmic_bytes_per_launch": round(by.value / max(n.value, 1)),
+                "launches_per_step": int(n.value), "avg_launch_us": round(ms.value * 1e3 / max(n.value, 1), 2),
                 "gemm_ms_per_step": round(ms.value, 3), "algorithmic_gflop_per_step": round(fl.value / 1e9, 1),
                 "algorithmic_gbytes_per_step": round(by.value / 1e9, 2),
                 "hbm_equiv_gbs": round(by.value / (ms.value * 1e-3) / 1e9, 1) if ms.value > 0 else 0.0}

@@ -1,4 +1,4 @@
-// HBM-bound kernels of the Paella hot path for gfx950: LayerNorm, depthwise 3x3 conv (+LN), GRN statistics,
+// HBM-bound kernels of the Paella hot path for gfx950: LayerNorm, VQGAN depthwise 3x3 conv, GRN statistics,
 // token-embedding gather, timestep embedding, layout shuffles.  All activations are NHWC fp32
 // ([rows = B*h*w, C] row-major), so every wave streams whole channel rows with 16-byte lanes and all
 // per-position reductions are wave64 shuffles (no LDS, no barriers) -- one wave per position.
@@ -99,89 +99,7 @@ int launch_layernorm(const float* x, float* y, int64_t rows, int C, float eps, f
     return PAELLA_OK;
 }
 
-// ---------------------------------------------------------------------------
-// UNet ResBlock front half (reference src/modules.py:46-47,55-58):
-//   depthwise Conv2d(k=3, zero padding, groups=C) + bias -> LayerNorm2d(C)
-// weights are repacked [tap][C] (tap = ky*3+kx); the skip variant (Conv2d(2C->C, groups=C) over
-// cat([x, skip])) is repacked [j][tap][C]: output channel g reads concatenated channels 2g+j.
-// ---------------------------------------------------------------------------
-template <int NV, bool SKIP>
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void dwconv_ln_kernel(const float* __restrict__ x,
-                                                                        const float* __restrict__ skip,
-                                                                        const float* __restrict__ w,
-                                                                        const float* __restrict__ bias,
-                                                                        float* __restrict__ y, int B, int H, int W, int C,
-                                                                        float eps) {
-    const int lane = threadIdx.x & 63;
-    const int64_t pos = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
-    const int64_t total = (int64_t)B * H * W;
-    if (pos >= total) return;
-    const int C4 = C >> 2;
-    const int xx = (int)(pos % W);
-    const int yy = (int)((pos / W) % H);
-    f32x4 acc[NV];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c4 = lane + i * 64;
-        acc[i] = c4 < C4 ? ld4(bias + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-        const int sy = yy + ky - 1;
-        if (sy < 0 || sy >= H) continue;
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const int sx = xx + kx - 1;
-            if (sx < 0 || sx >= W) continue;
-            const int64_t npos = pos + (int64_t)(ky - 1) * W + (kx - 1);
-            const int tap = ky * 3 + kx;
-#pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                const int c4 = lane + i * 64;
-                if (c4 >= C4) continue;
-                if (!SKIP) {
-                    acc[i] += ld4(x + npos * C + c4 * 4) * ld4(w + tap * C + c4 * 4);
-                } else {
-                    // out channels g..g+3 (g = 4*c4) read cat channels 2g..2g+7
-                    const int cc = 8 * c4;
-                    const float* src = cc < C ? (x + npos * C + cc) : (skip + npos * C + (cc - C));
-                    const f32x4 e0 = ld4(src), e1 = ld4(src + 4);
-                    const f32x4 w0 = ld4(w + tap * C + c4 * 4);
-                    const f32x4 w1 = ld4(w + (9 + tap) * C + c4 * 4);
-                    acc[i][0] += e0[0] * w0[0] + e0[1] * w1[0];
-                    acc[i][1] += e0[2] * w0[1] + e0[3] * w1[1];
-                    acc[i][2] += e1[0] * w0[2] + e1[1] * w1[2];
-                    acc[i][3] += e1[2] * w0[3] + e1[3] * w1[3];
-                }
-            }
-        }
-    }
-    ln_regs<NV>(acc, C4, lane, C, eps, 1.0f, 0.0f);
-    float* yr = y + pos * C;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c4 = lane + i * 64;
-        if (c4 < C4) st4(yr + c4 * 4, acc[i]);
-    }
-}
-
-// (superseded on the per-step path by the workgroup-per-position kernel in dwconv.hip; kept as the
-//  large-batch / bandwidth-bound variant and as a cross-check in the tests)
-int launch_dwconv_ln_onewave(const float* x, const float* skip, const float* w, const float* bias, float* y, int B, int H,
-                             int W, int C, float eps, hipStream_t st) {
-    const int64_t total = (int64_t)B * H * W;
-    if (total <= 0) return PAELLA_OK;
-    if ((C & 3) || (skip && (C & 7))) { paella_set_error("dwconv_ln: bad channel count %d", C); return PAELLA_ERR_ARG; }
-    const unsigned blocks = (unsigned)((total + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
-    if (skip)
-        DISPATCH_NV(C >> 2, hipLaunchKernelGGL((dwconv_ln_kernel<NV, true>), dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, st,
-                                               x, skip, w, bias, y, B, H, W, C, eps));
-    else
-        DISPATCH_NV(C >> 2, hipLaunchKernelGGL((dwconv_ln_kernel<NV, false>), dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, st,
-                                               x, skip, w, bias, y, B, H, W, C, eps));
-    LAUNCH_CHECK_RET();
-    return PAELLA_OK;
-}
+// (the UNet ResBlock front half -- depthwise 3x3 + LayerNorm -- lives in dwconv.hip)
 
 // ---------------------------------------------------------------------------
 // VQGAN ResBlock depthwise half (reference src/vqgan.py:11-14,38):
