@@ -2,7 +2,10 @@
 // (reference src/modules.py:7-19 Attention2D, :65-79 AttnBlock, nn.MultiheadAttention semantics;
 //  utils/alter_attention.py:19-36 for the optional post-softmax per-key weights).
 //
-// One wave owns 16 query rows of one (sample, head).  Both contractions run on the exact-fp32
+// One WORKGROUP owns 16 query rows of one (sample, head); its 4 waves split the key tiles (wave w takes tiles w, w+4, ...)
+// and merge their online-softmax states (m, l, O) through LDS in fixed wave order -- at batch-1 sampling sizes
+// (64 queries x 68 keys) the kernel is a latency chain, so the chain is cut 4x and 4x more CUs are engaged.
+// Both contractions run on the exact-fp32
 // matrix cores (v_mfma_f32_16x16x4_f32) in "transposed" form so that no cross-lane data movement
 // is needed between them:
 //   S^T[key][q]  = K . Q^T    -> lane (r16, kq) holds S^T[key = 4*kq + r][q = r16]
@@ -20,8 +23,7 @@ template <int DT>  // DT = head_dim / 16
 __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int q0 = (blockIdx.x * 4 + wave) * 16;
-    if (q0 >= a.Lq) return;
+    const int q0 = blockIdx.x * 16;
     const int h = blockIdx.y, b = blockIdx.z;
     const int r16 = lane & 15, kq = lane >> 4;
     constexpr int D = DT * 16;
@@ -112,26 +114,47 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
 
     f32x4 kfA[DT], kfB[DT];
     float vfA[DT][4], vfB[DT][4];
-    load_tile(0, kfA, vfA);
-    for (int kt = 0; kt < ntiles; kt += 2) {
-        load_tile(kt + 1, kfB, vfB);
+    // this wave's key tiles: wave, wave + 4, ... (software pipelined, two register sets)
+    load_tile(wave, kfA, vfA);
+    for (int kt = wave; kt < ntiles; kt += 8) {
+        load_tile(kt + 4, kfB, vfB);
         __builtin_amdgcn_sched_barrier(0);
         process(kt, kfA, vfA);
-        if (kt + 1 < ntiles) {  // wave-uniform
-            load_tile(kt + 2, kfA, vfA);
+        if (kt + 4 < ntiles) {  // wave-uniform
+            load_tile(kt + 8, kfA, vfA);
             __builtin_amdgcn_sched_barrier(0);
-            process(kt + 1, kfB, vfB);
+            process(kt + 4, kfB, vfB);
         }
     }
     float l = l_run;
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
-    const float inv = 1.0f / l;
-    const int q = q0 + r16;
-    if (q < a.Lq) {
-        float* op = a.out + ((size_t)b * a.Lq + q) * a.ldo + h * D + kq * 4;
+
+    // ---- merge the 4 waves' (m, l, O^T) in fixed order ----
+    __shared__ float s_m[4][64], s_l[4][64];
+    __shared__ __attribute__((aligned(16))) float s_o[4][DT][64][4];
+    s_m[wave][lane] = m_run;
+    s_l[wave][lane] = l;
 #pragma unroll
-        for (int j = 0; j < DT; ++j) *reinterpret_cast<f32x4*>(op + j * 16) = oacc[j] * inv;
+    for (int j = 0; j < DT; ++j) *reinterpret_cast<f32x4*>(&s_o[wave][j][lane][0]) = oacc[j];
+    __syncthreads();
+    float mw[4], m_all = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { mw[w] = s_m[w][lane]; m_all = fmaxf(m_all, mw[w]); }
+    float l_all = 0.f, f[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        f[w] = expf(mw[w] - m_all);  // empty waves: exp(-inf) = 0
+        l_all += s_l[w][lane] * f[w];
+    }
+    const float inv = 1.0f / l_all;
+    const int q = q0 + r16;
+    // wave w finalises the output d-tiles j = w, w+4, ...
+    for (int j = wave; j < DT; j += 4) {
+        f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < 4; ++w) o += *reinterpret_cast<const f32x4*>(&s_o[w][j][lane][0]) * f[w];
+        if (q < a.Lq) *reinterpret_cast<f32x4*>(a.out + ((size_t)b * a.Lq + q) * a.ldo + h * D + kq * 4 + j * 16) = o * inv;
     }
 }
 
@@ -147,7 +170,7 @@ int launch_attention(const AttnArgs& a, hipStream_t st) {
         return PAELLA_ERR_ARG;
     }
     if (a.key_weights && (a.n_kw > a.Lself + a.Lcond || a.n_kw < 1)) { paella_set_error("attention: attn_weights longer than the key sequence"); return PAELLA_ERR_ARG; }
-    dim3 grid((a.Lq + 63) / 64, a.nhead, a.B);
+    dim3 grid((a.Lq + 15) / 16, a.nhead, a.B);
     switch (a.D / 16) {
         case 1: hipLaunchKernelGGL((attention_kernel<1>), grid, dim3(256), 0, st, a); break;
         case 2: hipLaunchKernelGGL((attention_kernel<2>), grid, dim3(256), 0, st, a); break;

@@ -25,13 +25,14 @@
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-template <int WM, int WN, int TM, int TN, int PD, bool APRO, bool GLDS>
+template <int WM, int WN, int TM, int TN, int PD, bool APRO, bool GLDS, int ABL = 0>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g, int kslice, int S, float* __restrict__ slabs,
                                                       int tiles_m, int tiles_n, unsigned* __restrict__ counters, unsigned slab_bytes) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16, BK = 32;
     constexpr int LA = (BM * 8 + 255) / 256, LB = (BN * 8 + 255) / 256;
     static_assert(WM * WN == 4, "4 waves per workgroup");
-    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * BK];
+    constexpr int NSTAGE = GLDS ? PD : 2;  // LDS stages: the GLDS variant uses PD as its LDS ring depth
+    __shared__ __attribute__((aligned(16))) float smem[NSTAGE * (BM + BN) * BK];
 
     // ---- XCD-aware tile id (bijective remap of blockIdx.x) ----
     const int nwg = tiles_m * tiles_n;
@@ -115,39 +116,90 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g, int kslice, in
     constexpr bool DUAL = (TM * TN == 1);
     f32x4 acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
     auto compute = [&](int t) {
-        const float* As = smem + (t & 1) * (BM + BN) * BK;
+        const float* As = smem + (GLDS ? (t % NSTAGE) : (t & 1)) * (BM + BN) * BK;
         const float* Bs = As + BM * BK;
-        f32x4 af[2][TM], bf[2][TN];
+        constexpr bool FRAG_FIRST = (TM * TN <= 2);  // small wave tiles: all fragment reads up front; big ones: per 16-k group (VGPRs)
+        if constexpr (FRAG_FIRST) {
+            f32x4 af[2][TM], bf[2][TN];
+            if (ABL == 3) {  // ablation: MFMA only, operands from registers
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int c4 = kk * 4 + kq;
+                for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int row = (wm * TM + i) * 16 + r16;
-                af[kk][i] = *reinterpret_cast<const f32x4*>(As + row * BK + ((c4 ^ (row & 7)) << 2));
+                    for (int i = 0; i < TM; ++i) af[kk][i] = f32x4{1.f, 2.f, 3.f, (float)t};
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) bf[kk][j] = f32x4{1.f, 2.f, (float)t, 4.f};
+                }
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const int c4 = kk * 4 + kq;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const int row = (wm * TM + i) * 16 + r16;
+                        af[kk][i] = *reinterpret_cast<const f32x4*>(As + row * BK + ((c4 ^ (row & 7)) << 2));
+                    }
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const int row = (wn * TN + j) * 16 + r16;
+                        bf[kk][j] = *reinterpret_cast<const f32x4*>(Bs + row * BK + ((c4 ^ (row & 7)) << 2));
+                    }
+                }
             }
+            if (ABL == 1) {  // ablation: no MFMA, keep the fragment reads alive
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int row = (wn * TN + j) * 16 + r16;
-                bf[kk][j] = *reinterpret_cast<const f32x4*>(Bs + row * BK + ((c4 ^ (row & 7)) << 2));
-            }
-        }
-        if (DUAL) {
+                for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[0][0][e], af[0][0][e], acc[0][0], 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[1][0][e], af[1][0][e], acc2, 0, 0, 0);
+                    for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(af[kk][i]));
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(bf[kk][j]));
+                }
+            } else if (DUAL) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[0][0][e], af[0][0][e], acc[0][0], 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[1][0][e], af[1][0][e], acc2, 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[kk][j][e], af[kk][i][e], acc[i][j], 0, 0, 0);
             }
         } else {
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
+            for (int kk = 0; kk < 2; ++kk) {
+                f32x4 af[TM], bf[TN];
+                const int c4 = kk * 4 + kq;
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
+                for (int i = 0; i < TM; ++i) {
+                    const int row = (wm * TM + i) * 16 + r16;
+                    af[i] = *reinterpret_cast<const f32x4*>(As + row * BK + ((c4 ^ (row & 7)) << 2));
+                }
 #pragma unroll
-                    for (int i = 0; i < TM; ++i)
+                for (int j = 0; j < TN; ++j) {
+                    const int row = (wn * TN + j) * 16 + r16;
+                    bf[j] = *reinterpret_cast<const f32x4*>(Bs + row * BK + ((c4 ^ (row & 7)) << 2));
+                }
+                if (ABL == 1) {
 #pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[kk][j][e], af[kk][i][e], acc[i][j], 0, 0, 0);
+                    for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(af[i]));
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(bf[j]));
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][e], af[i][e], acc[i][j], 0, 0, 0);
+                }
+            }
         }
     };
 
@@ -160,7 +212,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g, int kslice, in
         // Requires K % 32 == 0 (no tail masking), no A prologue, BM and BN multiples of 32 -- checked by the launcher.
         const int swz = (tid & 7) ^ ((tid >> 3) & 7);
         auto glds_tile = [&](int t) {
-            float* As = smem + (t & 1) * (BM + BN) * BK;
+            float* As = smem + (t % NSTAGE) * (BM + BN) * BK;
             float* Bs = As + BM * BK;
             const int kc = min(kbeg + t * BK, g.K - BK) + swz * 4;
 #pragma unroll
@@ -172,15 +224,26 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g, int kslice, in
                 __builtin_amdgcn_global_load_lds((const void*)(bptr[i] + kc),
                                                  (__attribute__((address_space(3))) void*)(Bs + (wave * 8 + i * 32) * BK), 16, 0, 0);
         };
-        glds_tile(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        // NSTAGE-deep LDS ring, NSTAGE-1 tiles of DMA in flight across the (raw) barrier: counted vmcnt, never 0 in the loop
+        // (guide 5 "Pipelining across barriers": __syncthreads() would drain the DMA queue, s_barrier does not).
+#pragma unroll
+        for (int j = 0; j < NSTAGE - 1; ++j) glds_tile(j);
         for (int t = 0; t < ntiles; ++t) {
-            glds_tile(t + 1);  // into the buffer every wave finished reading before the previous barrier
+            // tile t has landed once at most NSTAGE-2 younger tiles (LA+LB DMA instructions each) are still outstanding
+            if constexpr ((NSTAGE - 2) * (LA + LB) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if constexpr ((NSTAGE - 2) * (LA + LB) == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else if constexpr ((NSTAGE - 2) * (LA + LB) == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else if constexpr ((NSTAGE - 2) * (LA + LB) == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if constexpr ((NSTAGE - 2) * (LA + LB) == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if constexpr ((NSTAGE - 2) * (LA + LB) == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();          // every wave's share of tile t is in LDS; every wave is done with tile t-1
+            glds_tile(t + NSTAGE - 1);             // refill the stage tile t-1 occupied
             compute(t);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
     } else {
     // invariant at the top of iteration t: tile t is in LDS[t&1]; R[(t+1)%PD .. (t+PD-1)%PD] hold tiles t+1..t+PD-1; R[t%PD] is free
 #pragma unroll
@@ -191,11 +254,11 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g, int kslice, in
     for (; t + PD <= ntiles; t += PD) {  // full chunks: no per-tile conditionals, one basic block per tile
 #pragma unroll
         for (int u = 0; u < PD; ++u) {
-            load_tile(R[u], t + u + PD);
+            if (ABL != 2) load_tile(R[u], t + u + PD);
             __builtin_amdgcn_sched_barrier(0);  // keep the prefetch above the MFMA block (hipcc sinks it otherwise)
             compute(t + u);
             __builtin_amdgcn_sched_barrier(0);
-            store_tile(R[(u + 1) % PD], t + u + 1);
+            if (ABL != 2) store_tile(R[(u + 1) % PD], t + u + 1);
             __syncthreads();
         }
     }
@@ -399,7 +462,7 @@ static void launch_one(const GemmArgs& g, int kslice, int S, float* slabs, hipSt
     if (g.a_scale)
         hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, PD, true, false>), grid, dim3(256), pad, st, g, kslice, S, slabs, tiles_m, tiles_n, counters, (unsigned)slab_bytes);
     else if (glds)
-        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, 1, false, kCanGlds>), grid, dim3(256), pad, st, g, kslice, S, slabs, tiles_m, tiles_n, counters, (unsigned)slab_bytes);
+        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, (BM + BN <= 64 ? 4 : (BM + BN <= 128 ? 3 : 2)), false, kCanGlds>), grid, dim3(256), pad, st, g, kslice, S, slabs, tiles_m, tiles_n, counters, (unsigned)slab_bytes);
     else
         hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, PD, false, false>), grid, dim3(256), pad, st, g, kslice, S, slabs, tiles_m, tiles_n, counters, (unsigned)slab_bytes);
     if (S > 1 && !counters)
@@ -536,6 +599,23 @@ static int launch_gemm_cfg_impl(const GemmArgs& g, int cfg, int splitk, void* ws
     int S = splitk;
     if (cfg < 0) choose_config(g.M, g.N, g.K, ws ? ws_bytes : 0, &cfg, &S);
     if (cfg >= 16 && cfg < 24) return launch_gemm_ws(g, (cfg - 16) >> 1, ((cfg - 16) & 1) + 1, S, ws, ws_bytes, st);
+    if (cfg >= 64) {  // ablation builds (tools only): cfg = 64 + 16*ABL + tile (tile in {2,5}); results are NOT a GEMM
+        const int abl = (cfg - 64) / 16, tile = (cfg - 64) % 16;
+        int kslice = ((g.K + (S < 1 ? 1 : S) - 1) / (S < 1 ? 1 : S) + 31) / 32 * 32;
+        const int Sx = (g.K + kslice - 1) / kslice;
+#define ABL_LAUNCH(WMv, WNv, TMv, TNv, A)                                                                                     \
+    do {                                                                                                                       \
+        constexpr int BM = WMv * TMv * 16, BN = WNv * TNv * 16;                                                                \
+        const int tm_ = (g.M + BM - 1) / BM, tn_ = (g.N + BN - 1) / BN;                                                        \
+        hipLaunchKernelGGL((gemm_nt_kernel<WMv, WNv, TMv, TNv, 2, false, false, A>), dim3(tm_ * tn_, Sx), dim3(256), 0, st, g, \
+                           kslice, Sx, reinterpret_cast<float*>(ws), tm_, tn_, (unsigned*)nullptr, 0u);                        \
+    } while (0)
+        if (tile == 5) { if (abl == 1) ABL_LAUNCH(2, 2, 1, 1, 1); else if (abl == 2) ABL_LAUNCH(2, 2, 1, 1, 2); else ABL_LAUNCH(2, 2, 1, 1, 3); }
+        else { if (abl == 1) ABL_LAUNCH(2, 2, 2, 2, 1); else if (abl == 2) ABL_LAUNCH(2, 2, 2, 2, 2); else ABL_LAUNCH(2, 2, 2, 2, 3); }
+#undef ABL_LAUNCH
+        LAUNCH_CHECK_RET();
+        return PAELLA_OK;
+    }
     const bool pd1 = cfg >= 32;
     if (pd1) cfg -= 32;
     if (cfg >= kNumCfgs) { paella_set_error("gemm: bad tile config %d", cfg); return PAELLA_ERR_ARG; }

@@ -85,6 +85,31 @@ def test_gemm_ws_split_reduce_is_repeatable(lib, cfg):
     assert all(torch.equal(outs[0], o) for o in outs[1:])
 
 
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 8])
+@pytest.mark.parametrize("splitk", [1, 4])
+def test_gemm_glds_ring(lib, cfg, splitk):
+    """Direct global->LDS staging path (multi-stage LDS ring, counted vmcnt): same results as the register-staged path."""
+    M, N, K = 200, 328, 1312  # K % 32 == 0 is required by this path
+    g = torch.Generator().manual_seed(cfg)
+    A = torch.randn(M, K, generator=g) + torch.arange(K)[None, :] * 0.01
+    W = torch.randn(N, K, generator=g) / 30 + torch.arange(N)[:, None] * 0.002
+    ref = (A.double() @ W.double().t()).float()
+    Ad, Wd = A.cuda(), W.cuda()
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    lib.paella_debug_set_spread(2)
+    try:
+        outs = []
+        for _ in range(4):
+            C = torch.full((M, N), float("nan"), device="cuda")
+            _check(lib, lib.paella_op_gemm(_p(Ad), _p(Wd), None, None, _p(C), M, N, K, 0, cfg, splitk, _p(ws), ws.numel(), _st()))
+            outs.append(C)
+        torch.cuda.synchronize()
+    finally:
+        lib.paella_debug_set_spread(0)
+    np.testing.assert_allclose(outs[0].cpu().numpy(), ref.numpy(), atol=2e-3, rtol=2e-5)
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+
+
 def test_gemm_is_run_to_run_deterministic(lib):
     M, N, K = 128, 1280, 5120
     g = torch.Generator().manual_seed(1)

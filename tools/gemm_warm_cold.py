@@ -20,8 +20,8 @@ def bench(M, N, K, cfg, sk, ncopy, reps=5):
         ts.append(e0.elapsed_time(e1) * 1e3 / n)
     return sorted(ts)[len(ts) // 2]
 for (M, N, K, cfg, sk) in [(128, 5120, 1280, 3, 2), (128, 5120, 1280, 4, 4), (32, 1280, 5120, 5, 16), (128, 1280, 1280, 5, 4), (512, 640, 2560, 5, 4), (128, 5120, 1280, 5, 1), (128, 5120, 1280, 2, 4), (32, 5120, 1280, 5, 4), (128, 1280, 5120, 5, 8), (512, 2560, 640, 5, 1), (1024, 5120, 1280, 2, 1)]:
-    lib.paella_debug_set_spread(4)
-    off = bench(M, N, K, cfg, sk, 28)
     lib.paella_debug_set_spread(0)
+    off = bench(M, N, K, cfg, sk, 28)
+    lib.paella_debug_set_spread(2)
     on = bench(M, N, K, cfg, sk, 28)
-    print("%5d x %5d x %5d cfg %d/%d: two-launch split-K %.1f us | in-launch sc1 combine %.1f us" % (M, N, K, cfg, sk, off, on), flush=True)
+    print("%5d x %5d x %5d cfg %d/%d: register ring %.1f us | glds LDS ring %.1f us" % (M, N, K, cfg, sk, off, on), flush=True)
