@@ -55,6 +55,7 @@ struct Epilogue {
     int sH, sW, sC;         // STORE_D2S / PIXSHUF: source grid (rows m=(b,y,x)), channels per segment
     int py, px;             // STORE_D2S: extra output offset (transposed-conv phase)
     int n_seg_x;            // STORE_D2S: segments along n are (dy,dx) with dx in [0,n_seg_x); 2 for k2s2, 1 for a phase
+    float* rowstat_out;     // optional [M, N/16, 2]: per row and 16-column block, (sum, sum of squares) of the stored values (LayerNorm-on-load)
     float* sumsq_out;       // optional [ceil(M/16), N]: per 16-row group, column sums of the stored values squared (GRN)
     int remap_in, remap_out, remap_off;  // STORE_PLAIN, remap_in > 0: out row = (m/remap_in)*remap_out + m%remap_in + remap_off
 };
@@ -63,7 +64,7 @@ static inline Epilogue make_epilogue() {
     Epilogue e;
     e.bias = nullptr; e.act = ACT_NONE; e.alpha = 1.f; e.residual = nullptr; e.ldr = 0;
     e.ts = nullptr; e.ts_stride = 0; e.rows_per_sample = 1; e.store_mode = STORE_PLAIN;
-    e.sH = e.sW = e.sC = 0; e.py = e.px = 0; e.n_seg_x = 2; e.remap_in = e.remap_out = e.remap_off = 0; e.sumsq_out = nullptr;
+    e.sH = e.sW = e.sC = 0; e.py = e.px = 0; e.n_seg_x = 2; e.remap_in = e.remap_out = e.remap_off = 0; e.sumsq_out = nullptr; e.rowstat_out = nullptr;
     return e;
 }
 
@@ -76,6 +77,11 @@ struct GemmArgs {
     const float* a_scale;      // [samples, K] or null
     const float* a_shift;      // [K]
     int a_rows_per_sample;
+    // or (exclusive with a_scale) LayerNorm of the A rows from producer statistics: a' = (a - mean[m]) * rstd[m],
+    // mean/var combined from ln_stats [M, ln_nblk, 2] (Epilogue::rowstat_out of the GEMM that produced A), K == 16*ln_nblk
+    const float* ln_stats;
+    int ln_nblk;
+    float ln_eps;
     Epilogue ep;
 };
 

@@ -25,7 +25,7 @@
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-template <int WM, int WN, int TM, int TN, int PD, bool APRO, bool GLDS, int ABL = 0>
+template <int WM, int WN, int TM, int TN, int PD, int APRO, bool GLDS, int ABL = 0>  // APRO: 0 none, 1 GRN scale/shift, 2 LayerNorm from row statistics
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g, int kslice, int S, float* __restrict__ slabs,
                                                       int tiles_m, int tiles_n, unsigned* __restrict__ counters, unsigned slab_bytes) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16, BK = 32;
@@ -67,16 +67,30 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g, int kslice, in
     // select-masked (a load under a lane condition, or a select on its result inside a conditional block, makes hipcc
     // wait for it at once); out-of-range rows only feed outputs that are never stored, and the K tail is zeroed on the
     // ACTIVATION side only when the tile is written to LDS.
-    struct Stage { f32x4 a[LA]; f32x4 s[APRO ? LA : 1]; f32x4 t; f32x4 b[LB]; };
+    struct Stage { f32x4 a[LA]; f32x4 s[APRO == 1 ? LA : 1]; f32x4 t; f32x4 b[LB]; };
     Stage R[PD];
     const float* aptr[LA];
-    const float* sptr[APRO ? LA : 1];
+    const float* sptr[APRO == 1 ? LA : 1];
     const float* bptr[LB];
+    float ln_mu[APRO == 2 ? LA : 1], ln_rs[APRO == 2 ? LA : 1];
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
         const int gmc = min(m0 + ldrow + i * 32, g.M - 1);
         aptr[i] = g.A + (size_t)gmc * g.lda;
-        if (APRO) sptr[i] = g.a_scale + (size_t)(gmc / g.a_rows_per_sample) * g.K;
+        if (APRO == 1) sptr[i] = g.a_scale + (size_t)(gmc / g.a_rows_per_sample) * g.K;
+        if (APRO == 2) {
+            // LayerNorm-on-load: combine the producer's per-16-column (sum, sumsq) partials of this row; the 8 lanes that
+            // share the row (tid & 7) split the blocks and xor-reduce.  fp64 for the final E[x^2] - mean^2.
+            const float* stp = g.ln_stats + (size_t)gmc * g.ln_nblk * 2;
+            double s = 0.0, q = 0.0;
+            for (int j = ldc4; j < g.ln_nblk; j += 8) { s += (double)stp[2 * j]; q += (double)stp[2 * j + 1]; }
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+            const double mean = s / (double)g.K;
+            const double var = q / (double)g.K - mean * mean;
+            ln_mu[i] = (float)mean;
+            ln_rs[i] = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + (double)g.ln_eps));
+        }
     }
 #pragma unroll
     for (int i = 0; i < LB; ++i) bptr[i] = g.W + (size_t)min(n0 + ldrow + i * 32, g.N - 1) * g.ldw;
@@ -86,9 +100,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g, int kslice, in
 #pragma unroll
         for (int i = 0; i < LA; ++i) {
             r.a[i] = *reinterpret_cast<const f32x4*>(aptr[i] + kc);
-            if (APRO) r.s[i] = *reinterpret_cast<const f32x4*>(sptr[i] + kc);
+            if (APRO == 1) r.s[i] = *reinterpret_cast<const f32x4*>(sptr[i] + kc);
         }
-        if (APRO) r.t = *reinterpret_cast<const f32x4*>(g.a_shift + kc);
+        if (APRO == 1) r.t = *reinterpret_cast<const f32x4*>(g.a_shift + kc);
 #pragma unroll
         for (int i = 0; i < LB; ++i) r.b[i] = *reinterpret_cast<const f32x4*>(bptr[i] + kc);
     };
@@ -100,7 +114,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g, int kslice, in
         for (int i = 0; i < LA; ++i) {
             const int row = ldrow + i * 32;
             f32x4 v = r.a[i];
-            if (APRO) v = v * r.s[i] + r.t;
+            if (APRO == 1) v = v * r.s[i] + r.t;
+            if (APRO == 2) v = (v - ln_mu[i]) * ln_rs[i];
             if (!kok) v = f32x4{0.f, 0.f, 0.f, 0.f};
             if (LA * 32 == BM || row < BM) *reinterpret_cast<f32x4*>(As + row * BK + ((ldc4 ^ (row & 7)) << 2)) = v;
         }
@@ -352,6 +367,17 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g, int kslice, in
                 const int mg = m0 + (wm * TM + i) * 16;
                 if (r16 == 0 && n < g.N && mg < g.M) *reinterpret_cast<f32x4*>(g.ep.sumsq_out + (size_t)(mg >> 4) * g.N + n) = q;
             }
+            if (g.ep.rowstat_out) {  // kernel-uniform: per-row (sum, sum of squares) over this 16-column block (LayerNorm-on-load)
+                float rs = (v[0] + v[1]) + (v[2] + v[3]);
+                float rq = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                rs += __shfl_xor(rs, 16, 64); rq += __shfl_xor(rq, 16, 64);
+                rs += __shfl_xor(rs, 32, 64); rq += __shfl_xor(rq, 32, 64);
+                const int nb = n0 + (wn * TN + j) * 16;
+                if (kq == 0 && m < g.M && nb < g.N) {
+                    float* dstp = g.ep.rowstat_out + ((size_t)m * (g.N >> 4) + (nb >> 4)) * 2;
+                    dstp[0] = rs; dstp[1] = rq;
+                }
+            }
         }
     }
 }
@@ -405,6 +431,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_frag_kernel(GemmArgs g, int
                 const int mg = m0 + (wm * TM + i) * 16;
                 if (r16 == 0 && n < g.N && mg < g.M) *reinterpret_cast<f32x4*>(g.ep.sumsq_out + (size_t)(mg >> 4) * g.N + n) = q;
             }
+            if (g.ep.rowstat_out) {  // kernel-uniform: per-row (sum, sum of squares) over this 16-column block (LayerNorm-on-load)
+                float rs = (v[0] + v[1]) + (v[2] + v[3]);
+                float rq = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                rs += __shfl_xor(rs, 16, 64); rq += __shfl_xor(rq, 16, 64);
+                rs += __shfl_xor(rs, 32, 64); rq += __shfl_xor(rq, 32, 64);
+                const int nb = n0 + (wn * TN + j) * 16;
+                if (kq == 0 && m < g.M && nb < g.N) {
+                    float* dstp = g.ep.rowstat_out + ((size_t)m * (g.N >> 4) + (nb >> 4)) * 2;
+                    dstp[0] = rs; dstp[1] = rq;
+                }
+            }
         }
     }
 }
@@ -455,16 +492,18 @@ static void launch_one(const GemmArgs& g, int kslice, int S, float* slabs, hipSt
         }
     }
     constexpr bool kCanGlds = (BM % 32 == 0) && (BN % 32 == 0);
-    const bool glds = kCanGlds && g_glds && !g.a_scale && (g.K % 32 == 0) && g.K >= 32;
+    const bool glds = kCanGlds && g_glds && !g.a_scale && !g.ln_stats && (g.K % 32 == 0) && g.K >= 32;
     unsigned* counters = nullptr;
     const size_t slab_bytes = (size_t)tiles_m * tiles_n * S * BM * BN * sizeof(float);
     if (S > 1 && g_combine && slab_bytes < ((size_t)1 << 31)) (void)gemm_tile_counters(&counters);
     if (g.a_scale)
-        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, PD, true, false>), grid, dim3(256), pad, st, g, kslice, S, slabs, tiles_m, tiles_n, counters, (unsigned)slab_bytes);
+        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, PD, 1, false>), grid, dim3(256), pad, st, g, kslice, S, slabs, tiles_m, tiles_n, counters, (unsigned)slab_bytes);
+    else if (g.ln_stats)
+        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, PD, 2, false>), grid, dim3(256), pad, st, g, kslice, S, slabs, tiles_m, tiles_n, counters, (unsigned)slab_bytes);
     else if (glds)
-        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, (BM + BN <= 64 ? 4 : (BM + BN <= 128 ? 3 : 2)), false, kCanGlds>), grid, dim3(256), pad, st, g, kslice, S, slabs, tiles_m, tiles_n, counters, (unsigned)slab_bytes);
+        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, (BM + BN <= 64 ? 4 : (BM + BN <= 128 ? 3 : 2)), 0, kCanGlds>), grid, dim3(256), pad, st, g, kslice, S, slabs, tiles_m, tiles_n, counters, (unsigned)slab_bytes);
     else
-        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, PD, false, false>), grid, dim3(256), pad, st, g, kslice, S, slabs, tiles_m, tiles_n, counters, (unsigned)slab_bytes);
+        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, PD, 0, false>), grid, dim3(256), pad, st, g, kslice, S, slabs, tiles_m, tiles_n, counters, (unsigned)slab_bytes);
     if (S > 1 && !counters)
         hipLaunchKernelGGL((splitk_reduce_frag_kernel<WM, WN, TM, TN>), dim3(tiles_m * tiles_n), dim3(256), 0, st, g, S, slabs, tiles_m, tiles_n);
 }
@@ -592,12 +631,17 @@ static int launch_gemm_cfg_impl(const GemmArgs& g, int cfg, int splitk, void* ws
                          g.M, g.N, g.K, g.lda, g.ldw, g.ldc);
         return PAELLA_ERR_ARG;
     }
+    if ((g.ep.rowstat_out && (g.N & 15)) || (g.ln_stats && (g.a_scale || g.K != 16 * g.ln_nblk))) {
+        paella_set_error("gemm: row statistics need N %% 16 == 0 and K == 16 * ln_nblk");
+        return PAELLA_ERR_ARG;
+    }
     if (g.ep.store_mode == STORE_D2S && (g.ep.sC & 3)) {
         paella_set_error("gemm: depth-to-space store needs channels %% 4 == 0");
         return PAELLA_ERR_ARG;
     }
     int S = splitk;
     if (cfg < 0) choose_config(g.M, g.N, g.K, ws ? ws_bytes : 0, &cfg, &S);
+    if (cfg >= 16 && cfg < 24 && (g.ep.rowstat_out || g.ln_stats)) { paella_set_error("gemm_ws: row statistics unsupported"); return PAELLA_ERR_ARG; }
     if (cfg >= 16 && cfg < 24) return launch_gemm_ws(g, (cfg - 16) >> 1, ((cfg - 16) & 1) + 1, S, ws, ws_bytes, st);
     if (cfg >= 64) {  // ablation builds (tools only): cfg = 64 + 16*ABL + tile (tile in {2,5}); results are NOT a GEMM
         const int abl = (cfg - 64) / 16, tile = (cfg - 64) % 16;
@@ -607,7 +651,7 @@ static int launch_gemm_cfg_impl(const GemmArgs& g, int cfg, int splitk, void* ws
     do {                                                                                                                       \
         constexpr int BM = WMv * TMv * 16, BN = WNv * TNv * 16;                                                                \
         const int tm_ = (g.M + BM - 1) / BM, tn_ = (g.N + BN - 1) / BN;                                                        \
-        hipLaunchKernelGGL((gemm_nt_kernel<WMv, WNv, TMv, TNv, 2, false, false, A>), dim3(tm_ * tn_, Sx), dim3(256), 0, st, g, \
+        hipLaunchKernelGGL((gemm_nt_kernel<WMv, WNv, TMv, TNv, 2, 0, false, A>), dim3(tm_ * tn_, Sx), dim3(256), 0, st, g, \
                            kslice, Sx, reinterpret_cast<float*>(ws), tm_, tn_, (unsigned*)nullptr, 0u);                        \
     } while (0)
         if (tile == 5) { if (abl == 1) ABL_LAUNCH(2, 2, 1, 1, 1); else if (abl == 2) ABL_LAUNCH(2, 2, 1, 1, 2); else ABL_LAUNCH(2, 2, 1, 1, 3); }

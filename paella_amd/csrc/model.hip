@@ -61,6 +61,8 @@ struct Block {
     bool ts_standalone = true; // BT_TS: false when fused into the previous block's GEMM epilogue
     int fused_ts = -1;         // BT_RES/BT_FF: ts offset fused into GEMM2, or -1
     int attn_index = -1;
+    bool emit_rowstat = false;   // producer: this block's last GEMM also writes per-row (sum, sumsq) partials of x
+    bool ln_from_stats = false;  // consumer (ATTN / UP): LayerNorm folded into the GEMM's A-operand load from those partials
     int c_from = 0, c_to = 0;  // samplers
 };
 
@@ -75,6 +77,7 @@ struct paella_unet {
     std::vector<int> attn_c;      // channel width per attention block (execution order)
     bool finalized = false;
     bool freqs_set = false;
+    bool clf_from_stats = false;
     int c_max = 0;
 };
 
@@ -212,6 +215,30 @@ static int build_plan(paella_unet* m) {
         }
     }
     m->ts_total = ts_total;
+    // LayerNorm-on-load planning: a consumer LN (AttnBlock, up-sampler, clf) whose input x was last written by a GEMM
+    // epilogue (ResBlock / FeedForward GEMM2 incl. a fused TimestepBlock, or an AttnBlock's out-projection) gets its row
+    // statistics from that epilogue and folds the normalisation into its own GEMM's operand load -- no LN launch.
+    {
+        std::vector<Block*> all;
+        for (Block& b : m->down) all.push_back(&b);
+        for (Block& b : m->up) all.push_back(&b);
+        auto producer_of = [&](size_t idx) -> Block* {
+            if (idx == 0) return nullptr;
+            Block* p = all[idx - 1];
+            if (p->type == BT_TS && !p->ts_standalone && idx >= 2) p = all[idx - 2];
+            else if (p->type == BT_TS) return nullptr;
+            if ((p->type == BT_RES || p->type == BT_FF || p->type == BT_ATTN) && (p->c % 16) == 0) return p;
+            return nullptr;
+        };
+        for (size_t i = 0; i < all.size(); ++i) {
+            Block* b = all[i];
+            if (b->type != BT_ATTN && b->type != BT_UP) continue;
+            Block* p = producer_of(i);
+            if (p && p->level == b->level) { p->emit_rowstat = true; b->ln_from_stats = true; }
+        }
+        Block* p = producer_of(all.size());
+        if (p && p->level == 0) { p->emit_rowstat = true; m->clf_from_stats = true; }
+    }
     m->n_attn = n_attn;
     m->c_max = 0;
     for (int i = 0; i < c.n_levels; ++i) m->c_max = c.c_hidden[i] > m->c_max ? c.c_hidden[i] : m->c_max;
@@ -374,7 +401,7 @@ extern "C" size_t paella_unet_cond_bytes(const paella_unet* m, int B, int S) {
 struct FwdBuffers {
     float* xl[PAELLA_MAX_LEVELS];
     float* xu[PAELLA_MAX_LEVELS];
-    float *h, *g, *grn_scale, *grn_gx, *ts, *remb, *splitk;
+    float *h, *g, *grn_scale, *grn_gx, *ts, *remb, *splitk, *rowstat;
     // cond_prepare
     float *c_embed, *c_silu, *kvm;
 };
@@ -407,6 +434,7 @@ static void carve_forward(const paella_unet* m, Arena& a, int B, int H, int W, i
     }
     f.ts = a.take((size_t)B * (m->ts_total > 0 ? m->ts_total : 1));
     f.remb = a.take((size_t)B * c.c_r);
+    f.rowstat = a.take(hmax / 8 + 64);  // [rows, C/16, 2]
     f.splitk = a.take(kSplitKBudget / sizeof(float));
     (void)S;
 }
@@ -559,6 +587,7 @@ static int run_mlp_block(FwdCtx& cx, const Block& b, float* x, const float* skip
     g2.a_rows_per_sample = rps;
     g2.ep.bias = T(m, b.prefix + ".channelwise.4.bias");
     g2.ep.residual = x; g2.ep.ldr = ch;
+    if (b.emit_rowstat) g2.ep.rowstat_out = cx.f.rowstat;
     if (b.fused_ts >= 0) {
         g2.ep.ts = cx.f.ts + b.fused_ts; g2.ep.ts_stride = m->ts_total; g2.ep.rows_per_sample = rps;
     }
@@ -573,9 +602,13 @@ static int run_attn_block(FwdCtx& cx, const Block& b, float* x, int h, int w) {
     const int64_t rows = (int64_t)cx.B * h * w;
     const int nh = m->cfg.nhead[b.level];
     const bool self = m->cfg.self_attn != 0;
-    RET_IF(launch_layernorm(x, cx.f.h, rows, ch, 1e-6f, 1.f, 0.f, 0, 0, 0, cx.st));
     const int nq = self ? 3 * ch : ch;
     GemmArgs gq = gemm_args(cx.f.h, ch, T(m, b.prefix + ".attention.attn.in_proj_weight"), ch, cx.f.g, nq, (int)rows, nq, ch);
+    if (b.ln_from_stats) {  // LayerNorm folded into the in-projection's operand load (statistics from the producer's epilogue)
+        gq.A = x; gq.ln_stats = cx.f.rowstat; gq.ln_nblk = ch / 16; gq.ln_eps = 1e-6f;
+    } else {
+        RET_IF(launch_layernorm(x, cx.f.h, rows, ch, 1e-6f, 1.f, 0.f, 0, 0, 0, cx.st));
+    }
     gq.ep.bias = T(m, b.prefix + ".attention.attn.in_proj_bias");
     RET_IF(launch_gemm(gq, cx.f.splitk, kSplitKBudget, cx.st));
     const float* kv = cx.cond + cond_offset_floats(m, b.attn_index, cx.B, cx.S);
@@ -591,6 +624,7 @@ static int run_attn_block(FwdCtx& cx, const Block& b, float* x, int h, int w) {
     GemmArgs go = gemm_args(cx.f.h, ch, T(m, b.prefix + ".attention.attn.out_proj.weight"), ch, x, ch, (int)rows, ch, ch);
     go.ep.bias = T(m, b.prefix + ".attention.attn.out_proj.bias");
     go.ep.residual = x; go.ep.ldr = ch;
+    if (b.emit_rowstat) go.ep.rowstat_out = cx.f.rowstat;
     RET_IF(launch_gemm(go, cx.f.splitk, kSplitKBudget, cx.st));
     return PAELLA_OK;
 }
@@ -661,9 +695,10 @@ extern "C" int paella_unet_forward(paella_unet* m, const int64_t* tokens, const 
         switch (b.type) {
             case BT_UP: {  // LayerNorm2d + ConvTranspose2d(k2,s2): GEMM with N = 4*c_to and a depth-to-space store
                 const int64_t rows_in = (int64_t)B * h * w;
-                RET_IF(launch_layernorm(x, f.h, rows_in, b.c_from, 1e-6f, 1.f, 0.f, 0, 0, 0, st));
                 float* dst = f.xu[b.level - 1];
                 GemmArgs g = gemm_args(f.h, b.c_from, T(m, b.prefix + ".1.weight"), b.c_from, dst, b.c_to, (int)rows_in, 4 * b.c_to, b.c_from);
+                if (b.ln_from_stats) { g.A = x; g.ln_stats = f.rowstat; g.ln_nblk = b.c_from / 16; g.ln_eps = 1e-6f; }
+                else RET_IF(launch_layernorm(x, f.h, rows_in, b.c_from, 1e-6f, 1.f, 0.f, 0, 0, 0, st));
                 g.ep.bias = T(m, b.prefix + ".1.bias");
                 g.ep.store_mode = STORE_D2S; g.ep.sH = h; g.ep.sW = w; g.ep.sC = b.c_to; g.ep.n_seg_x = 2;
                 RET_IF(launch_gemm(g, f.splitk, kSplitKBudget, st));
@@ -682,9 +717,10 @@ extern "C" int paella_unet_forward(paella_unet* m, const int64_t* tokens, const 
     }
     // ---- clf + out_mapper (src/modules.py:179-187) ----
     {
-        RET_IF(launch_layernorm(x, f.h, n0, c.c_hidden[0], 1e-6f, 1.f, 0.f, 0, 0, 0, st));
         const int p2 = p * p;
         GemmArgs g = gemm_args(f.h, c.c_hidden[0], T(m, "clf.1.weight"), c.c_hidden[0], f.g, c.c_out, (int)n0, c.c_out * p2, c.c_hidden[0]);
+        if (m->clf_from_stats) { g.A = x; g.ln_stats = f.rowstat; g.ln_nblk = c.c_hidden[0] / 16; g.ln_eps = 1e-6f; }
+        else RET_IF(launch_layernorm(x, f.h, n0, c.c_hidden[0], 1e-6f, 1.f, 0.f, 0, 0, 0, st));
         g.ep.bias = T(m, "clf.1.bias");
         if (p == 2) { g.ep.store_mode = STORE_D2S; g.ep.sH = h0; g.ep.sW = w0; g.ep.sC = c.c_out; g.ep.n_seg_x = 2; }
         RET_IF(launch_gemm(g, f.splitk, kSplitKBudget, st));
