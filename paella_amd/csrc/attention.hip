@@ -19,11 +19,14 @@
 #include "common.h"
 #include <math.h>
 
-template <int DT>  // DT = head_dim / 16
+// KSPLIT = true : one workgroup per 16 queries, its 4 waves split the key tiles (latency-bound small grids)
+// KSPLIT = false: one workgroup per 64 queries, each wave owns 16 queries and walks all key tiles (K/V re-read 16x less)
+template <int DT, bool KSPLIT>  // DT = head_dim / 16
 __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int q0 = blockIdx.x * 16;
+    const int q0 = KSPLIT ? blockIdx.x * 16 : (blockIdx.x * 4 + wave) * 16;
+    if (!KSPLIT && q0 >= a.Lq) return;
     const int h = blockIdx.y, b = blockIdx.z;
     const int r16 = lane & 15, kq = lane >> 4;
     constexpr int D = DT * 16;
@@ -114,21 +117,33 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
 
     f32x4 kfA[DT], kfB[DT];
     float vfA[DT][4], vfB[DT][4];
-    // this wave's key tiles: wave, wave + 4, ... (software pipelined, two register sets)
-    load_tile(wave, kfA, vfA);
-    for (int kt = wave; kt < ntiles; kt += 8) {
-        load_tile(kt + 4, kfB, vfB);
+    // this wave's key tiles: KSPLIT -> wave, wave + 4, ...; else all of them (software pipelined, two register sets)
+    constexpr int KSTEP = KSPLIT ? 4 : 1;
+    const int kt0 = KSPLIT ? wave : 0;
+    load_tile(kt0, kfA, vfA);
+    for (int kt = kt0; kt < ntiles; kt += 2 * KSTEP) {
+        load_tile(kt + KSTEP, kfB, vfB);
         __builtin_amdgcn_sched_barrier(0);
         process(kt, kfA, vfA);
-        if (kt + 4 < ntiles) {  // wave-uniform
-            load_tile(kt + 8, kfA, vfA);
+        if (kt + KSTEP < ntiles) {  // wave-uniform
+            load_tile(kt + 2 * KSTEP, kfA, vfA);
             __builtin_amdgcn_sched_barrier(0);
-            process(kt + 4, kfB, vfB);
+            process(kt + KSTEP, kfB, vfB);
         }
     }
     float l = l_run;
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
+    if constexpr (!KSPLIT) {
+        const float inv1 = 1.0f / l;
+        const int q1 = q0 + r16;
+        if (q1 < a.Lq) {
+            float* op = a.out + ((size_t)b * a.Lq + q1) * a.ldo + h * D + kq * 4;
+#pragma unroll
+            for (int j = 0; j < DT; ++j) *reinterpret_cast<f32x4*>(op + j * 16) = oacc[j] * inv1;
+        }
+        return;
+    }
 
     // ---- merge the 4 waves' (m, l, O^T) in fixed order ----
     __shared__ float s_m[4][64], s_l[4][64];
@@ -170,16 +185,21 @@ int launch_attention(const AttnArgs& a, hipStream_t st) {
         return PAELLA_ERR_ARG;
     }
     if (a.key_weights && (a.n_kw > a.Lself + a.Lcond || a.n_kw < 1)) { paella_set_error("attention: attn_weights longer than the key sequence"); return PAELLA_ERR_ARG; }
-    dim3 grid((a.Lq + 15) / 16, a.nhead, a.B);
+    // small query counts (batch-1 sampling grids) are latency chains -> split keys over waves; large ones re-read K/V
+    // once per workgroup, so give a workgroup 64 queries instead
+    const bool ksplit = a.Lq < 256;
+    dim3 grid(ksplit ? (a.Lq + 15) / 16 : (a.Lq + 63) / 64, a.nhead, a.B);
+#define ATT_CASE(n)                                                                                        \
+    case n:                                                                                                \
+        if (ksplit) hipLaunchKernelGGL((attention_kernel<n, true>), grid, dim3(256), 0, st, a);            \
+        else hipLaunchKernelGGL((attention_kernel<n, false>), grid, dim3(256), 0, st, a);                  \
+        break;
     switch (a.D / 16) {
-        case 1: hipLaunchKernelGGL((attention_kernel<1>), grid, dim3(256), 0, st, a); break;
-        case 2: hipLaunchKernelGGL((attention_kernel<2>), grid, dim3(256), 0, st, a); break;
-        case 3: hipLaunchKernelGGL((attention_kernel<3>), grid, dim3(256), 0, st, a); break;
-        case 4: hipLaunchKernelGGL((attention_kernel<4>), grid, dim3(256), 0, st, a); break;
-        case 5: hipLaunchKernelGGL((attention_kernel<5>), grid, dim3(256), 0, st, a); break;
-        case 6: hipLaunchKernelGGL((attention_kernel<6>), grid, dim3(256), 0, st, a); break;
-        case 7: hipLaunchKernelGGL((attention_kernel<7>), grid, dim3(256), 0, st, a); break;
-        case 8: hipLaunchKernelGGL((attention_kernel<8>), grid, dim3(256), 0, st, a); break;
+        ATT_CASE(1) ATT_CASE(2) ATT_CASE(3) ATT_CASE(4) ATT_CASE(5) ATT_CASE(6) ATT_CASE(7) ATT_CASE(8)
+    }
+#undef ATT_CASE
+    switch (0) {
+        default: break;
     }
     LAUNCH_CHECK_RET();
     return PAELLA_OK;

@@ -172,3 +172,39 @@ def test_1b_forward_ragged_conditioning_vs_oracle(built_lib):
     clear, near, n_near = argmax_report(ref, got)
     print("1B forward: logit std %.3f, max|diff| %.3e, argmax mismatches clear=%d near-tie=%d" % (ref.std().item(), diff, clear, near))
     assert diff <= 1e-3 * max(1.0, ref.std().item()) and clear == 0
+
+
+def test_570m_64x64_grid_vs_oracle(built_lib):
+    """BASELINE config 3 geometry (512 px = 64x64 tokens) at batch 1: level-1 attention has 256 queries (query-parallel kernel path)."""
+    cfg = G.UNET_570M
+    m = paella_amd.Paella(**cfg)
+    sd = weights_for(m, sum(cfg["blocks"]))
+    m = m.to(DEV)
+    g = torch.Generator().manual_seed(8)
+    x = torch.randint(0, 8192, (1, 64, 64), generator=g)
+    r = torch.tensor([0.35])
+    c = cond_for(cfg, 1, 3, 0, G.COND_SEED)
+    with torch.no_grad():
+        ref = O.unet_forward(sd, cfg, x, r, **c)
+    got = m(x.to(DEV), r.to(DEV), **to_dev(c, DEV)).float().cpu()
+    diff = (got - ref).abs().max().item()
+    clear, near, n_near = argmax_report(ref, got)
+    print("570M 64x64: logit std %.3f, max|diff| %.3e, argmax mismatches clear=%d near-tie=%d of %d" % (ref.std().item(), diff, clear, near, 64 * 64))
+    assert diff <= 1e-3 * max(1.0, ref.std().item()) and clear == 0
+
+
+def test_large_grid_properties(built_lib):
+    """BASELINE config 5 geometry (128x128 tokens) on a narrow model: finite, deterministic, batch rows independent."""
+    cfg = dict(G.UNET_MID)
+    m = paella_amd.Paella(**cfg)
+    weights_for(m, sum(cfg["blocks"]))
+    m = m.to(DEV)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randint(0, cfg["num_labels"], (2, 128, 128), generator=g).to(DEV)
+    r = torch.tensor([0.7, 0.2], device=DEV)
+    c = to_dev(cond_for(cfg, 2, 40, 1, 5), DEV)
+    a = m(x, r, **c)
+    assert torch.isfinite(a).all() and a.shape == (2, cfg["num_labels"], 128, 128)
+    assert torch.equal(a, m(x, r, **c))
+    c0 = {k: (v[:1] if v is not None else None) for k, v in c.items()}
+    assert torch.allclose(a[:1], m(x[:1], r[:1], **c0), atol=1e-5)
