@@ -91,8 +91,8 @@ int launch_gemm(const GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t stream
 // Forces a specific tile config / split (for the autotuner and tests). cfg < 0 -> heuristic.
 int launch_gemm_cfg(const GemmArgs& g, int cfg, int splitk, void* ws, size_t ws_bytes, hipStream_t stream);
 size_t gemm_splitk_ws_bytes(int M, int N, int K);
-// weight-streaming kernel (gemm_ws.hip): tm_code 0..3 -> BM = 16,32,64,128; tn 1|2 -> BN = 64|128; in-launch split-K reduce
-int launch_gemm_ws(const GemmArgs& g, int tm_code, int tn, int splitk, void* ws, size_t ws_bytes, hipStream_t stream);
+// weight-streaming kernel (gemm_ws.hip): tm_code 0..2 -> BM = 16,32,64; nk_code 0..2 -> K-slice capacity 128,192,320; in-launch split-K reduce
+int launch_gemm_ws(const GemmArgs& g, int tm_code, int nk_code, int splitk, void* ws, size_t ws_bytes, hipStream_t stream);
 
 // LayerNorm over the channel dimension of [rows, C]; no learned affine (eps 1e-6),
 // optional scalar affine y = ln(x)*(1+g0)+g1 (VQGAN), optional space-to-depth gather:

@@ -641,8 +641,7 @@ static int launch_gemm_cfg_impl(const GemmArgs& g, int cfg, int splitk, void* ws
     }
     int S = splitk;
     if (cfg < 0) choose_config(g.M, g.N, g.K, ws ? ws_bytes : 0, &cfg, &S);
-    if (cfg >= 16 && cfg < 24 && (g.ep.rowstat_out || g.ln_stats)) { paella_set_error("gemm_ws: row statistics unsupported"); return PAELLA_ERR_ARG; }
-    if (cfg >= 16 && cfg < 24) return launch_gemm_ws(g, (cfg - 16) >> 1, ((cfg - 16) & 1) + 1, S, ws, ws_bytes, st);
+    if (cfg >= 16 && cfg < 25) return launch_gemm_ws(g, (cfg - 16) / 3, (cfg - 16) % 3, S, ws, ws_bytes, st);
     if (cfg >= 64) {  // ablation builds (tools only): cfg = 64 + 16*ABL + tile (tile in {2,5}); results are NOT a GEMM
         const int abl = (cfg - 64) / 16, tile = (cfg - 64) % 16;
         int kslice = ((g.K + (S < 1 ? 1 : S) - 1) / (S < 1 ? 1 : S) + 31) / 32 * 32;

@@ -49,7 +49,7 @@ def test_gemm_heuristic(lib, M, N, K):
     np.testing.assert_allclose(C.cpu().numpy(), ref.numpy(), atol=2e-5 * max(1, K ** 0.5 / 8), rtol=1e-5)
 
 
-@pytest.mark.parametrize("cfg", list(range(9)) + list(range(16, 24)) + [34, 36, 37])
+@pytest.mark.parametrize("cfg", list(range(9)) + list(range(16, 25)) + [34, 36, 37])
 @pytest.mark.parametrize("splitk", [1, 3])
 def test_gemm_every_tile_config(lib, cfg, splitk):
     M, N, K = 200, 328, 416  # ragged in every dimension
@@ -66,7 +66,7 @@ def test_gemm_every_tile_config(lib, cfg, splitk):
     np.testing.assert_allclose(C.cpu().numpy(), ref.numpy(), atol=1e-3, rtol=2e-5)
 
 
-@pytest.mark.parametrize("cfg", range(16, 24))
+@pytest.mark.parametrize("cfg", range(16, 25))
 def test_gemm_ws_split_reduce_is_repeatable(lib, cfg):
     """In-launch split-K (last-arriver reduce): many back-to-back launches give bit-identical, correct results."""
     M, N, K = 96, 640, 2560
