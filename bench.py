@@ -57,6 +57,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the informational batched-throughput run")
     ap.add_argument("--extra-batch", type=int, default=8)
+    ap.add_argument("--force-dist", action="store_true", help="take the torch.distributed (RCCL) path even at world size 1 (launch under torchrun)")
     return ap.parse_args()
 
 
@@ -112,7 +113,7 @@ def cpu_baseline(model_cfg, vq_cfg, grid, sample_steps, unet_sd, vq_sd, cond, un
 
 def main():
     a = parse()
-    distributed = a.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1
+    distributed = a.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1 or (a.force_dist and "RANK" in os.environ)
     rank, world, local = 0, 1, 0
     if distributed:
         rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
@@ -221,7 +222,7 @@ def main():
         extra = {"batch": eb, "images_per_sec": round(eb * k / dte, 3), "ms_per_image": round(dte / (eb * k) * 1e3, 3)}
 
     cpu = None
-    if rank == 0 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:  # the CPU baseline is an N = 1 figure
         try:
             cpu = cpu_baseline(mcfg, vcfg, a.grid, a.sample_steps, unet_sd, vq_sd, cond_all, uncond_all)
         except Exception as e:  # the baseline is informational; never lose the GPU line over it

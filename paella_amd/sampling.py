@@ -218,7 +218,8 @@ class GraphSampler:
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread_local: a process-group watchdog thread polling events must not invalidate the capture
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.out = self._run()
         torch.cuda.synchronize(self.device)
 
