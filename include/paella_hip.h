@@ -189,6 +189,9 @@ int paella_prof_collect(double* total_ms, double* total_flops, double* total_byt
 int paella_debug_launch_chain(float* buf, int n_elems, int blocks, int n_launches, void* stream);
 /* A/B switch for the GEMM workgroup-spreading LDS reservation (default on) */
 int paella_debug_set_spread(int on);
+/* Timeline probe (tools/gemm_timeline.py): device buffer of 8 x uint64 per workgroup that the probe build of the GEMM
+ * (tile config 128 + tile) fills with 100 MHz wall-clock stamps; NULL switches it off. */
+int paella_debug_set_trace(void* dev_buf);
 
 #ifdef __cplusplus
 }

@@ -25,6 +25,15 @@
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+// timeline probe (tools/gemm_timeline.py): ABL == 4 builds stamp wall_clock64() (100 MHz) at six points per workgroup
+__device__ unsigned long long* g_trace_ptr = nullptr;
+#define TRACE_STAMP(i)                                                                                                      \
+    do {                                                                                                                    \
+        if constexpr (ABL == 4) {                                                                                           \
+            if (threadIdx.x == 0 && g_trace_ptr) g_trace_ptr[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = wall_clock64(); \
+        }                                                                                                                   \
+    } while (0)
+
 template <int WM, int WN, int TM, int TN, int PD, int APRO, bool GLDS, int ABL = 0>  // APRO: 0 none, 1 GRN scale/shift, 2 LayerNorm from row statistics
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g, int kslice, int S, float* __restrict__ slabs,
                                                       int tiles_m, int tiles_n, unsigned* __restrict__ counters, unsigned slab_bytes) {
@@ -48,6 +57,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g, int kslice, in
     const int kbeg = blockIdx.y * kslice;
     const int kend = min(g.K, kbeg + kslice);
 
+    TRACE_STAMP(0);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -106,8 +116,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g, int kslice, in
 #pragma unroll
         for (int i = 0; i < LB; ++i) r.b[i] = *reinterpret_cast<const f32x4*>(bptr[i] + kc);
     };
-    auto store_tile = [&](const Stage& r, int t) {
-        float* As = smem + (t & 1) * (BM + BN) * BK;
+    auto store_tile_slot = [&](const Stage& r, int t, int slot) {
+        float* As = smem + slot * (BM + BN) * BK;
         float* Bs = As + BM * BK;
         const bool kok = kbeg + t * BK + ldc4 * 4 < kend;
 #pragma unroll
@@ -125,6 +135,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g, int kslice, in
             if (LB * 32 == BN || row < BN) *reinterpret_cast<f32x4*>(Bs + row * BK + ((ldc4 ^ (row & 7)) << 2)) = r.b[i];
         }
     };
+    auto store_tile = [&](const Stage& r, int t) { store_tile_slot(r, t, t & 1); };
     // All fragment reads of the tile are issued up front (one exposed LDS latency per tile, not one per 16-k group),
     // and a 1x1 wave tile alternates two accumulators so its MFMAs are never back-to-back dependent
     // (v_mfma_f32_16x16x4_f32: 32-cycle issue, 40-cycle dependent latency).
@@ -265,6 +276,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g, int kslice, in
     for (int j = 0; j < PD; ++j) load_tile(R[j], j);
     store_tile(R[0], 0);
     __syncthreads();
+    TRACE_STAMP(1);
     int t = 0;
     for (; t + PD <= ntiles; t += PD) {  // full chunks: no per-tile conditionals, one basic block per tile
 #pragma unroll
@@ -289,6 +301,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g, int kslice, in
     }
 
     if (DUAL) acc[0][0] += acc2;
+    TRACE_STAMP(2);
 
     // ---- split-K: write this slice's fp32 slab in fragment order (fully coalesced); splitk_reduce_frag_kernel sums the
     // slabs in fixed slice order and runs the epilogue.  (An in-launch "last arriver" combine was measured 1.7x SLOWER
@@ -316,9 +329,11 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g, int kslice, in
                                                        mybase + ((i * TN + j) * 64 + lane) * 16, 0, 16);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        TRACE_STAMP(3);
         unsigned* sflag = reinterpret_cast<unsigned*>(smem);
         if (tid == 0) sflag[0] = __hip_atomic_fetch_add(counters + bid, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
+        TRACE_STAMP(4);
         if (sflag[0] != (unsigned)(S - 1)) return;
         if (tid == 0) __hip_atomic_store(counters + bid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
         const unsigned tbase = (unsigned)(((size_t)bid * S * (4 * FR) + (size_t)wave * FR) * sizeof(float));
@@ -380,6 +395,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g, int kslice, in
             }
         }
     }
+    if constexpr (ABL == 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TRACE_STAMP(5);
 }
 
 // Split-K reducer: one workgroup per output tile, same thread -> element mapping as gemm_nt_kernel, so every slab
@@ -473,6 +490,11 @@ static int g_combine = 1;  // in-launch split-K combine with write-through (sc1)
 static int g_glds = 0;  // measured neutral-to-negative on MI355X for these shapes (tools/gemm_warm_cold.py); kept for A/B
 // debug switches for A/B measurements: bit 0 = workgroup spreading (LDS reservation), bit 1 = direct global->LDS staging
 // bit 2 (value 4) = DISABLE the in-launch split-K combine (use the two-launch reducer)
+extern "C" int paella_debug_set_trace(void* dev_buf) {
+    unsigned long long* p = reinterpret_cast<unsigned long long*>(dev_buf);
+    HIP_CHECK_RET(hipMemcpyToSymbol(HIP_SYMBOL(g_trace_ptr), &p, sizeof(p)));
+    return PAELLA_OK;
+}
 extern "C" int paella_debug_set_spread(int on) { g_spread = on & 1; g_glds = (on >> 1) & 1; g_combine = ((on >> 2) & 1) ? 0 : 1; return PAELLA_OK; }
 
 template <int WM, int WN, int TM, int TN, int PD>
@@ -653,6 +675,21 @@ static int launch_gemm_cfg_impl(const GemmArgs& g, int cfg, int splitk, void* ws
         hipLaunchKernelGGL((gemm_nt_kernel<WMv, WNv, TMv, TNv, 2, 0, false, A>), dim3(tm_ * tn_, Sx), dim3(256), 0, st, g, \
                            kslice, Sx, reinterpret_cast<float*>(ws), tm_, tn_, (unsigned*)nullptr, 0u);                        \
     } while (0)
+        if (abl == 4) {  // timeline probe: the real kernel (in-launch combine) with time stamps
+            unsigned* ctr = nullptr;
+            if (Sx > 1) RET_IF_G(gemm_tile_counters(&ctr));
+#define TL_LAUNCH(WMv, WNv, TMv, TNv)                                                                                          \
+    do {                                                                                                                       \
+        constexpr int BM = WMv * TMv * 16, BN = WNv * TNv * 16;                                                                \
+        const int tm_ = (g.M + BM - 1) / BM, tn_ = (g.N + BN - 1) / BN;                                                        \
+        hipLaunchKernelGGL((gemm_nt_kernel<WMv, WNv, TMv, TNv, 2, 0, false, 4>), dim3(tm_ * tn_, Sx), dim3(256), 0, st, g,     \
+                           kslice, Sx, reinterpret_cast<float*>(ws), tm_, tn_, ctr, (unsigned)((size_t)tm_ * tn_ * Sx * BM * BN * 4)); \
+    } while (0)
+            if (tile == 5) TL_LAUNCH(2, 2, 1, 1); else TL_LAUNCH(2, 2, 2, 2);
+#undef TL_LAUNCH
+            LAUNCH_CHECK_RET();
+            return PAELLA_OK;
+        }
         if (tile == 5) { if (abl == 1) ABL_LAUNCH(2, 2, 1, 1, 1); else if (abl == 2) ABL_LAUNCH(2, 2, 1, 1, 2); else ABL_LAUNCH(2, 2, 1, 1, 3); }
         else { if (abl == 1) ABL_LAUNCH(2, 2, 2, 2, 1); else if (abl == 2) ABL_LAUNCH(2, 2, 2, 2, 2); else ABL_LAUNCH(2, 2, 2, 2, 3); }
 #undef ABL_LAUNCH
