@@ -58,6 +58,13 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g, int kslice, in
     const int kend = min(g.K, kbeg + kslice);
 
     TRACE_STAMP(0);
+    if constexpr (ABL == 4) {  // where did this workgroup run?  slot 6: HW_ID (wave/simd/cu/sh/se), slot 7: XCC_ID
+        if (threadIdx.x == 0 && g_trace_ptr) {
+            unsigned long long* tp = g_trace_ptr + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+            tp[6] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+            tp[7] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        }
+    }
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
