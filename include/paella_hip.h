@@ -103,6 +103,13 @@ int paella_unet_r_embedding(paella_unet* m, const float* r, int B, float max_pos
 int paella_unet_forward(paella_unet* m, const int64_t* tokens, const float* r, const void* cond, int B, int H, int W,
                         int S, const float* attn_weights, int n_attn_weights, float* logits_out, void* ws,
                         size_t ws_bytes, void* stream);
+/* The same evaluation when rows b and b + n_unique carry IDENTICAL tokens and r (classifier-free guidance: the conditional
+ * and unconditional passes of src/utils.py:44-46 batched as 2 x n_unique rows).  The blocks ahead of the first attention
+ * block never see the conditioning and are computed once for the n_unique distinct rows.  n_unique must divide B;
+ * n_unique == B is paella_unet_forward. */
+int paella_unet_forward_shared(paella_unet* m, const int64_t* tokens, const float* r, const void* cond, int B, int n_unique,
+                               int H, int W, int S, const float* attn_weights, int n_attn_weights, float* logits_out,
+                               void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Sampling tail and add_noise (reference src/utils.py:45-54; src/modules.py:277-283)

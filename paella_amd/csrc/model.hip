@@ -632,6 +632,16 @@ static int run_attn_block(FwdCtx& cx, const Block& b, float* x, int h, int w) {
 extern "C" int paella_unet_forward(paella_unet* m, const int64_t* tokens, const float* r, const void* cond, int B, int H, int W,
                                    int S, const float* attn_weights, int n_attn_weights, float* logits_out, void* ws,
                                    size_t ws_bytes, void* stream) {
+    return paella_unet_forward_shared(m, tokens, r, cond, B, B, H, W, S, attn_weights, n_attn_weights, logits_out, ws, ws_bytes, stream);
+}
+
+// Classifier-free guidance evaluates the SAME tokens and timestep against two conditionings (reference src/utils.py:44-46).
+// Everything before the first attention block never sees the conditioning, so with n_unique < B (rows b and b + n_unique carry
+// identical tokens / r) that prefix -- embedding, level-0 ResBlocks, the first down-sampler and ResBlock of level 1 -- is computed
+// for the n_unique distinct rows only and replicated (activations, saved skips, LayerNorm statistics) where the paths diverge.
+extern "C" int paella_unet_forward_shared(paella_unet* m, const int64_t* tokens, const float* r, const void* cond, int B, int n_unique,
+                                          int H, int W, int S, const float* attn_weights, int n_attn_weights, float* logits_out,
+                                          void* ws, size_t ws_bytes, void* stream) {
     if (!m || !m->finalized) { paella_set_error("model not finalized"); return PAELLA_ERR_STATE; }
     if (!tokens || !r || !logits_out) { paella_set_error("null argument"); return PAELLA_ERR_ARG; }
     const paella_unet_config& c = m->cfg;
@@ -650,10 +660,16 @@ extern "C" int paella_unet_forward(paella_unet* m, const int64_t* tokens, const 
     if (!a.ok || !ws) { paella_set_error("workspace too small (%zu needed, %zu given)", a.off, ws_bytes); return PAELLA_ERR_WORKSPACE; }
     hipStream_t st = cx.st;
     FwdBuffers& f = cx.f;
+    int split = -1;  // index in m->down of the first block that reads the conditioning
+    for (size_t i = 0; i < m->down.size(); ++i)
+        if (m->down[i].type == BT_ATTN) { split = (int)i; break; }
+    if (n_unique <= 0 || n_unique > B || B % n_unique) { paella_set_error("n_unique must divide B"); return PAELLA_ERR_ARG; }
+    const int Bfull = B;
+    if (split > 0 && n_unique < B) { B = n_unique; cx.B = n_unique; }  // shared prefix on the distinct rows only
 
     // timestep embedding + all TimestepBlock mappers
     if (m->ts_total > 0)
-        RET_IF(launch_timestep(r, m->freqs.p, m->ts_w.p, m->ts_b.p, f.ts, B, c.c_r, m->ts_total, 10000.0f, f.remb, st));
+        RET_IF(launch_timestep(r, m->freqs.p, m->ts_w.p, m->ts_b.p, f.ts, Bfull, c.c_r, m->ts_total, 10000.0f, f.remb, st));
 
     // in_mapper + PixelUnshuffle + embedding conv + LayerNorm2d   (src/modules.py:126-134,271)
     const int h0 = H / p, w0 = W / p;
@@ -669,7 +685,26 @@ extern "C" int paella_unet_forward(paella_unet* m, const int64_t* tokens, const 
     // ---- down ----
     float* x = f.xl[0];
     int h = h0, w = w0;
-    for (const Block& b : m->down) {
+    for (size_t bi = 0; bi < m->down.size(); ++bi) {
+        const Block& b = m->down[bi];
+        if ((int)bi == split && B != Bfull) {
+            // the paths diverge here: replicate the current activation, every saved skip and the LayerNorm statistics
+            const int reps = Bfull / B;
+            int lvl = 0;
+            for (size_t j = 0; j < bi; ++j) if (m->down[j].type == BT_DOWN) lvl = m->down[j].level;
+            for (int rep = 1; rep < reps; ++rep) {
+                for (int l = 0; l <= lvl; ++l) {
+                    const int64_t rows_l = (int64_t)B * (h0 >> l) * (w0 >> l);
+                    const int cl = c.c_hidden[l];
+                    RET_IF(launch_copy_rows(f.xl[l], cl, f.xl[l] + (size_t)rep * rows_l * cl, cl, rows_l, cl, st));
+                }
+                const int64_t rows_c = (int64_t)B * h * w;
+                const int sc = c.c_hidden[lvl] / 16 * 2;
+                if (f.rowstat && c.c_hidden[lvl] % 16 == 0)
+                    RET_IF(launch_copy_rows(f.rowstat, sc, f.rowstat + (size_t)rep * rows_c * sc, sc, rows_c, sc, st));
+            }
+            B = Bfull; cx.B = Bfull;
+        }
         switch (b.type) {
             case BT_DOWN: {  // LayerNorm2d + Conv2d(k2,s2): LN fused with the space-to-depth gather, then a GEMM
                 const int64_t rows_in = (int64_t)B * h * w;
@@ -718,6 +753,7 @@ extern "C" int paella_unet_forward(paella_unet* m, const int64_t* tokens, const 
     // ---- clf + out_mapper (src/modules.py:179-187) ----
     {
         const int p2 = p * p;
+        const int64_t n0 = (int64_t)B * h0 * w0;  // full batch again
         GemmArgs g = gemm_args(f.h, c.c_hidden[0], T(m, "clf.1.weight"), c.c_hidden[0], f.g, c.c_out, (int)n0, c.c_out * p2, c.c_hidden[0]);
         if (m->clf_from_stats) { g.A = x; g.ln_stats = f.rowstat; g.ln_nblk = c.c_hidden[0] / 16; g.ln_eps = 1e-6f; }
         else RET_IF(launch_layernorm(x, f.h, n0, c.c_hidden[0], 1e-6f, 1.f, 0.f, 0, 0, 0, st));

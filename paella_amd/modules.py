@@ -303,8 +303,10 @@ class Paella(nn.Module):
         return out
 
     # ------------------------------------------------------------------ forward
-    def forward_prepared(self, x, r, cond, attn_weights=None, out=None):
+    def forward_prepared(self, x, r, cond, attn_weights=None, out=None, n_unique=None):
         """One denoising evaluation against a `CondCache`. x int64 [B,H,W]; r fp32 [B].
+        n_unique < B promises that rows b and b + n_unique hold identical tokens and r (classifier-free guidance batches
+        the conditional and unconditional pass that way): the conditioning-independent prefix is then computed once.
         Returns logits with the reference's shape [B, num_labels, H, W] (a channels-last view of the
         position-major buffer the kernels write; pass `out` = a [B,H,W,num_labels] fp32 tensor to reuse memory)."""
         h = self._engine()
@@ -328,9 +330,12 @@ class Paella(nn.Module):
             raise ValueError("out must be a contiguous fp32 [B,H,W,num_labels] tensor")
         with torch.cuda.device(dev):
             ws = self._workspace(lib.paella_unet_workspace_bytes(h, B, H, W, cond.S))
-            _lib.check(lib.paella_unet_forward(h, _lib.ptr(x), _lib.ptr(r), _lib.ptr(cond.buf), B, H, W, cond.S, _lib.ptr(aw),
-                                               0 if aw is None else aw.numel(), _lib.ptr(out), _lib.ptr(ws), ws.numel(),
-                                               _lib.stream_ptr(dev)))
+            nu = B if n_unique is None else int(n_unique)
+            if nu <= 0 or B % nu:
+                raise ValueError("n_unique must divide the batch")
+            _lib.check(lib.paella_unet_forward_shared(h, _lib.ptr(x), _lib.ptr(r), _lib.ptr(cond.buf), B, nu, H, W, cond.S, _lib.ptr(aw),
+                                                      0 if aw is None else aw.numel(), _lib.ptr(out), _lib.ptr(ws), ws.numel(),
+                                                      _lib.stream_ptr(dev)))
         return out.permute(0, 3, 1, 2)
 
     def forward(self, x, r, byt5, clip=None, clip_image=None, x_cat=None, **kwargs):

@@ -111,8 +111,9 @@ def _sample_core(model, model_inputs, unconditional_inputs, latent_shape, init_x
             use_cfg = cfgs[i] is not None
             if native:
                 if use_cfg and batched:
+                    # both halves hold the same tokens / r: the library computes the conditioning-free prefix once
                     model.forward_prepared(torch.cat([sampled, sampled], dim=0), torch.cat([r, r]), cond_both,
-                                           attn_weights=attn_weights, out=logits2)
+                                           attn_weights=attn_weights, out=logits2, n_unique=B)
                     lc, lu = logits2[:B], logits2[B:]
                 else:
                     model.forward_prepared(sampled, r, cond_c, attn_weights=attn_weights, out=logits_c)

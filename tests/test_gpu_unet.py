@@ -208,3 +208,30 @@ def test_large_grid_properties(built_lib):
     assert torch.equal(a, m(x, r, **c))
     c0 = {k: (v[:1] if v is not None else None) for k, v in c.items()}
     assert torch.allclose(a[:1], m(x[:1], r[:1], **c0), atol=1e-5)
+
+
+@pytest.mark.parametrize("cfg_name", ["UNET_TINY", "UNET_MID", "UNET_570M"])
+def test_shared_cfg_prefix_matches_full_evaluation(built_lib, cfg_name):
+    """Classifier-free guidance batches cond + uncond rows with identical tokens / r; computing the conditioning-free prefix
+    once (n_unique = B/2) must give the logits of the plain 2B-row evaluation."""
+    cfg = dict(getattr(G, cfg_name))
+    m = paella_amd.Paella(**cfg)
+    weights_for(m, sum(cfg["blocks"]))
+    m = m.to(DEV)
+    B = 2 if cfg_name != "UNET_570M" else 1
+    g = torch.Generator().manual_seed(11)
+    x = torch.randint(0, cfg["num_labels"], (B, 16, 16), generator=g).to(DEV)
+    r = torch.rand(B, generator=g).to(DEV)
+    c = to_dev(cond_for(cfg, B, 3, 0, 21), DEV)
+    u = to_dev(cond_for(cfg, B, 3, 0, 22), DEV)
+    both = {k: (torch.cat([c[k], u[k]]) if c[k] is not None else None) for k in c}
+    cache = m.prepare_cond(**both)
+    x2, r2 = torch.cat([x, x]), torch.cat([r, r])
+    full = m.forward_prepared(x2, r2, cache).clone()
+    shared = m.forward_prepared(x2, r2, cache, n_unique=B)
+    assert torch.isfinite(shared).all()
+    scale = max(1.0, full.std().item())
+    assert (full - shared).abs().max().item() <= 2e-5 * scale
+    assert not torch.equal(shared[:B], shared[B:])  # the two halves really saw different conditioning
+    with pytest.raises(ValueError):
+        m.forward_prepared(x2, r2, cache, n_unique=3 if 2 * B % 3 else 5)
