@@ -106,10 +106,14 @@ int paella_unet_forward(paella_unet* m, const int64_t* tokens, const float* r, c
 /* The same evaluation when rows b and b + n_unique carry IDENTICAL tokens and r (classifier-free guidance: the conditional
  * and unconditional passes of src/utils.py:44-46 batched as 2 x n_unique rows).  The blocks ahead of the first attention
  * block never see the conditioning and are computed once for the n_unique distinct rows.  n_unique must divide B;
- * n_unique == B is paella_unet_forward. */
+ * n_unique == B with mix_c == mix_u == 0 is paella_unet_forward.
+ * (mix_c, mix_u) != (0, 0) (needs B == 2 * n_unique) additionally folds the guidance mix of src/utils.py:47 through the
+ * bias-free linear head (out_mapper, src/modules.py:184-187): logits_out then holds only the n_unique rows
+ * mix_c * logits(cond) + mix_u * logits(uncond), fp32 [n_unique,H,W,num_labels], equal to mixing the two outputs up to
+ * fp32 rounding. */
 int paella_unet_forward_shared(paella_unet* m, const int64_t* tokens, const float* r, const void* cond, int B, int n_unique,
-                               int H, int W, int S, const float* attn_weights, int n_attn_weights, float* logits_out,
-                               void* ws, size_t ws_bytes, void* stream);
+                               float mix_c, float mix_u, int H, int W, int S, const float* attn_weights,
+                               int n_attn_weights, float* logits_out, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Sampling tail and add_noise (reference src/utils.py:45-54; src/modules.py:277-283)

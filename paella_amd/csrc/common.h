@@ -131,6 +131,7 @@ int launch_scale_shift(float* x, const float* ts, int ts_stride, int64_t rows, i
 
 int launch_silu(const float* x, float* y, int64_t n, hipStream_t stream);
 int launch_copy_rows(const float* src, int lds, float* dst, int ldd, int64_t rows, int cols, hipStream_t stream);
+int launch_axpby(float* x, const float* y, float a, float b, int64_t n, hipStream_t stream);  // x = a*x + b*y
 
 // Attention over [self keys | conditioning keys] (reference src/modules.py:7-19,65-79;
 // utils/alter_attention.py:4-43). q/k/v are column blocks of row-major buffers.

@@ -430,6 +430,20 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict_
         dst[r * ldd + c] = src[r * lds_ + c];
     }
 }
+// x = a*x + b*y over n floats (n % 4 == 0): classifier-free-guidance mix of the two halves ahead of the linear head
+__global__ __launch_bounds__(256) void axpby_kernel(float* __restrict__ x, const float* __restrict__ y, float a, float b, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) st4(x + i * 4, ld4(x + i * 4) * a + ld4(y + i * 4) * b);
+}
+int launch_axpby(float* x, const float* y, float a, float b, int64_t n, hipStream_t st) {
+    if (n <= 0) return PAELLA_OK;
+    if (n & 3) { paella_set_error("axpby: n %% 4 != 0"); return PAELLA_ERR_ARG; }
+    int64_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, y, a, b, n / 4);
+    LAUNCH_CHECK_RET();
+    return PAELLA_OK;
+}
+
 int launch_copy_rows(const float* src, int lds_, float* dst, int ldd, int64_t rows, int cols, hipStream_t st) {
     if (rows <= 0 || cols <= 0) return PAELLA_OK;
     int64_t blocks = (rows * cols + 255) / 256;

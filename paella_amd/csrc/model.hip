@@ -632,16 +632,19 @@ static int run_attn_block(FwdCtx& cx, const Block& b, float* x, int h, int w) {
 extern "C" int paella_unet_forward(paella_unet* m, const int64_t* tokens, const float* r, const void* cond, int B, int H, int W,
                                    int S, const float* attn_weights, int n_attn_weights, float* logits_out, void* ws,
                                    size_t ws_bytes, void* stream) {
-    return paella_unet_forward_shared(m, tokens, r, cond, B, B, H, W, S, attn_weights, n_attn_weights, logits_out, ws, ws_bytes, stream);
+    return paella_unet_forward_shared(m, tokens, r, cond, B, B, 0.f, 0.f, H, W, S, attn_weights, n_attn_weights, logits_out, ws, ws_bytes, stream);
 }
 
 // Classifier-free guidance evaluates the SAME tokens and timestep against two conditionings (reference src/utils.py:44-46).
 // Everything before the first attention block never sees the conditioning, so with n_unique < B (rows b and b + n_unique carry
 // identical tokens / r) that prefix -- embedding, level-0 ResBlocks, the first down-sampler and ResBlock of level 1 -- is computed
 // for the n_unique distinct rows only and replicated (activations, saved skips, LayerNorm statistics) where the paths diverge.
+// The guidance mix l = mix_c * l_cond + mix_u * l_uncond (src/utils.py:47) can ride through the bias-free linear head
+// (out_mapper, src/modules.py:184-187): with (mix_c, mix_u) != (0, 0) and B == 2 * n_unique the head runs once on
+// mix_c * LN(z_cond) + mix_u * LN(z_uncond) and logits_out receives the n_unique MIXED rows (half the head FLOPs and logits bytes).
 extern "C" int paella_unet_forward_shared(paella_unet* m, const int64_t* tokens, const float* r, const void* cond, int B, int n_unique,
-                                          int H, int W, int S, const float* attn_weights, int n_attn_weights, float* logits_out,
-                                          void* ws, size_t ws_bytes, void* stream) {
+                                          float mix_c, float mix_u, int H, int W, int S, const float* attn_weights,
+                                          int n_attn_weights, float* logits_out, void* ws, size_t ws_bytes, void* stream) {
     if (!m || !m->finalized) { paella_set_error("model not finalized"); return PAELLA_ERR_STATE; }
     if (!tokens || !r || !logits_out) { paella_set_error("null argument"); return PAELLA_ERR_ARG; }
     const paella_unet_config& c = m->cfg;
@@ -664,6 +667,8 @@ extern "C" int paella_unet_forward_shared(paella_unet* m, const int64_t* tokens,
     for (size_t i = 0; i < m->down.size(); ++i)
         if (m->down[i].type == BT_ATTN) { split = (int)i; break; }
     if (n_unique <= 0 || n_unique > B || B % n_unique) { paella_set_error("n_unique must divide B"); return PAELLA_ERR_ARG; }
+    const bool mix = mix_c != 0.f || mix_u != 0.f;
+    if (mix && B != 2 * n_unique) { paella_set_error("guidance mix needs B == 2 * n_unique"); return PAELLA_ERR_ARG; }
     const int Bfull = B;
     if (split > 0 && n_unique < B) { B = n_unique; cx.B = n_unique; }  // shared prefix on the distinct rows only
 
@@ -760,8 +765,12 @@ extern "C" int paella_unet_forward_shared(paella_unet* m, const int64_t* tokens,
         g.ep.bias = T(m, "clf.1.bias");
         if (p == 2) { g.ep.store_mode = STORE_D2S; g.ep.sH = h0; g.ep.sW = w0; g.ep.sC = c.c_out; g.ep.n_seg_x = 2; }
         RET_IF(launch_gemm(g, f.splitk, kSplitKBudget, st));
-        const int64_t nt = (int64_t)B * H * W;
+        int64_t nt = (int64_t)B * H * W;
         RET_IF(launch_layernorm(f.g, f.h, nt, c.c_out, 1e-6f, 1.f, 0.f, 0, 0, 0, st));
+        if (mix) {  // the head is linear and bias-free: mix its input instead of its output
+            nt /= 2;
+            RET_IF(launch_axpby(f.h, f.h + (size_t)nt * c.c_out, mix_c, mix_u, nt * c.c_out, st));
+        }
         GemmArgs go = gemm_args(f.h, c.c_out, T(m, "out_mapper.1.weight"), c.c_out, logits_out, c.num_labels, (int)nt, c.num_labels, c.c_out);
         RET_IF(launch_gemm(go, f.splitk, kSplitKBudget, st));
     }

@@ -303,10 +303,12 @@ class Paella(nn.Module):
         return out
 
     # ------------------------------------------------------------------ forward
-    def forward_prepared(self, x, r, cond, attn_weights=None, out=None, n_unique=None):
+    def forward_prepared(self, x, r, cond, attn_weights=None, out=None, n_unique=None, cfg_mix=None):
         """One denoising evaluation against a `CondCache`. x int64 [B,H,W]; r fp32 [B].
         n_unique < B promises that rows b and b + n_unique hold identical tokens and r (classifier-free guidance batches
         the conditional and unconditional pass that way): the conditioning-independent prefix is then computed once.
+        cfg_mix=(a, b) with B == 2*n_unique folds the guidance mix a*logits[:B/2] + b*logits[B/2:] (src/utils.py:47) through
+        the bias-free linear head and returns only those B/2 mixed rows.
         Returns logits with the reference's shape [B, num_labels, H, W] (a channels-last view of the
         position-major buffer the kernels write; pass `out` = a [B,H,W,num_labels] fp32 tensor to reuse memory)."""
         h = self._engine()
@@ -324,16 +326,20 @@ class Paella(nn.Module):
         aw = self._f32(attn_weights, "attn_weights")
         if aw is not None and aw.dim() != 1:
             raise ValueError("attn_weights must be 1-D (utils/alter_attention.py:27)")
+        nu = B if n_unique is None else int(n_unique)
+        if nu <= 0 or B % nu:
+            raise ValueError("n_unique must divide the batch")
+        mix = (0.0, 0.0) if cfg_mix is None else (float(cfg_mix[0]), float(cfg_mix[1]))
+        if cfg_mix is not None and (B != 2 * nu or mix == (0.0, 0.0)):
+            raise ValueError("cfg_mix needs B == 2 * n_unique and a non-zero mix")
+        Bo = nu if cfg_mix is not None else B
         if out is None:
-            out = torch.empty(B, H, W, self.num_labels, dtype=torch.float32, device=dev)
-        elif tuple(out.shape) != (B, H, W, self.num_labels) or out.dtype != torch.float32 or not out.is_contiguous():
+            out = torch.empty(Bo, H, W, self.num_labels, dtype=torch.float32, device=dev)
+        elif tuple(out.shape) != (Bo, H, W, self.num_labels) or out.dtype != torch.float32 or not out.is_contiguous():
             raise ValueError("out must be a contiguous fp32 [B,H,W,num_labels] tensor")
         with torch.cuda.device(dev):
             ws = self._workspace(lib.paella_unet_workspace_bytes(h, B, H, W, cond.S))
-            nu = B if n_unique is None else int(n_unique)
-            if nu <= 0 or B % nu:
-                raise ValueError("n_unique must divide the batch")
-            _lib.check(lib.paella_unet_forward_shared(h, _lib.ptr(x), _lib.ptr(r), _lib.ptr(cond.buf), B, nu, H, W, cond.S, _lib.ptr(aw),
+            _lib.check(lib.paella_unet_forward_shared(h, _lib.ptr(x), _lib.ptr(r), _lib.ptr(cond.buf), B, nu, mix[0], mix[1], H, W, cond.S, _lib.ptr(aw),
                                                       0 if aw is None else aw.numel(), _lib.ptr(out), _lib.ptr(ws), ws.numel(),
                                                       _lib.stream_ptr(dev)))
         return out.permute(0, 3, 1, 2)

@@ -111,10 +111,13 @@ def _sample_core(model, model_inputs, unconditional_inputs, latent_shape, init_x
             use_cfg = cfgs[i] is not None
             if native:
                 if use_cfg and batched:
-                    # both halves hold the same tokens / r: the library computes the conditioning-free prefix once
-                    model.forward_prepared(torch.cat([sampled, sampled], dim=0), torch.cat([r, r]), cond_both,
-                                           attn_weights=attn_weights, out=logits2, n_unique=B)
-                    lc, lu = logits2[:B], logits2[B:]
+                    # both halves hold the same tokens / r: the library computes the conditioning-free prefix once.
+                    # With the counter-based generator (no bit-parity promise towards torch's RNG stream) a categorical
+                    # step also lets the guidance mix ride through the linear head: one mixed logits tensor comes back.
+                    fold = (not explicit) and noise == "philox" and temperatures[i] != 0
+                    model.forward_prepared(torch.cat([sampled, sampled], dim=0), torch.cat([r, r]), cond_both, attn_weights=attn_weights,
+                                           out=logits2[:B] if fold else logits2, n_unique=B, cfg_mix=cfgs[i] if fold else None)
+                    lc, lu = logits2[:B], (None if fold else logits2[B:])
                 else:
                     model.forward_prepared(sampled, r, cond_c, attn_weights=attn_weights, out=logits_c)
                     lc, lu = logits_c, None

@@ -235,3 +235,28 @@ def test_shared_cfg_prefix_matches_full_evaluation(built_lib, cfg_name):
     assert not torch.equal(shared[:B], shared[B:])  # the two halves really saw different conditioning
     with pytest.raises(ValueError):
         m.forward_prepared(x2, r2, cache, n_unique=3 if 2 * B % 3 else 5)
+
+
+def test_guidance_mix_through_linear_head(built_lib):
+    """cfg_mix folds l_c*a + l_u*b (src/utils.py:47) through the bias-free head: equal to mixing the two logits tensors."""
+    cfg = dict(G.UNET_MID)
+    m = paella_amd.Paella(**cfg)
+    weights_for(m, sum(cfg["blocks"]))
+    m = m.to(DEV)
+    B = 2
+    g = torch.Generator().manual_seed(5)
+    x = torch.randint(0, cfg["num_labels"], (B, 16, 16), generator=g).to(DEV)
+    r = torch.rand(B, generator=g).to(DEV)
+    c = to_dev(cond_for(cfg, B, 3, 0, 31), DEV)
+    u = to_dev(cond_for(cfg, B, 3, 0, 32), DEV)
+    both = {k: (torch.cat([c[k], u[k]]) if c[k] is not None else None) for k in c}
+    cache = m.prepare_cond(**both)
+    x2, r2 = torch.cat([x, x]), torch.cat([r, r])
+    full = m.forward_prepared(x2, r2, cache).clone()
+    a, b = 8.0, -7.0
+    ref = full[:B] * a + full[B:] * b
+    mixed = m.forward_prepared(x2, r2, cache, n_unique=B, cfg_mix=(a, b))
+    assert mixed.shape == ref.shape
+    assert (mixed - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    with pytest.raises(ValueError):
+        m.forward_prepared(x2, r2, cache, cfg_mix=(a, b))  # needs n_unique = B/2
