@@ -579,7 +579,7 @@ static void choose_config(int M, int N, int K, size_t ws_bytes, int* cfg_out, in
         const long t = tiles_of(5);
         if (t < 1024) {
             while (ktiles / S > 20 && S < 16) S *= 2;
-            while (t * S < 512 && S < 16 && ktiles / (S * 2) >= 5) S *= 2;
+            while (t * S < (t >= 512 ? 1024 : 512) && S < 16 && ktiles / (S * 2) >= 5) S *= 2;
             while (S > 1 && t * S > 2560) S /= 2;
         }
     }

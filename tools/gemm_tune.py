@@ -21,6 +21,10 @@ SHAPES = {
     "embed 512x640x1024": (512, 640, 1024), "down1 128x1280x2560": (128, 1280, 2560), "down2 32x1280x5120": (32, 1280, 5120),
     "up2 32x5120x1280": (32, 5120, 1280), "up1 128x2560x1280": (128, 2560, 1280), "clf 512x1024x640": (512, 1024, 640),
     "out 2048x8192x256": (2048, 8192, 256),
+    # shared classifier-free-guidance prefix (distinct rows only) and the folded head
+    "pfx L0 mlp1 256x2560x640": (256, 2560, 640), "pfx L0 mlp2 256x640x2560": (256, 640, 2560), "pfx embed 256x640x1024": (256, 640, 1024),
+    "pfx down1 64x1280x2560": (64, 1280, 2560), "pfx L1 mlp1 64x5120x1280": (64, 5120, 1280), "pfx L1 mlp2 64x1280x5120": (64, 1280, 5120),
+    "head 1024x8192x256": (1024, 8192, 256),
     "b8 L0 mlp1 4096x2560x640": (4096, 2560, 640), "b8 L0 mlp2 4096x640x2560": (4096, 640, 2560),
     "b8 L1 mlp1 1024x5120x1280": (1024, 5120, 1280), "b8 L1 mlp2 1024x1280x5120": (1024, 1280, 5120),
     "b8 L2 mlp1 256x5120x1280": (256, 5120, 1280), "b8 L2 mlp2 256x1280x5120": (256, 1280, 5120),
@@ -33,12 +37,15 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=None)
     ap.add_argument("--iters", type=int, default=30)
+    ap.add_argument("--only", default=None, help="substring filter on the shape name")
     a = ap.parse_args()
     lib = _lib.load()
     st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     ws = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
     results = {}
     for name, (M, N, K) in SHAPES.items():
+        if a.only and a.only not in name:
+            continue
         # cold weights without a flush kernel: rotate over enough distinct copies of W to exceed the 256 MiB MALL,
         # exactly like consecutive layers of the model; activations stay warm.  One event pair brackets a whole
         # rotation of back-to-back launches, so the figure includes the real launch boundaries.
