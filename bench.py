@@ -41,6 +41,7 @@ VQ = {"570m": dict(levels=3, bottleneck_blocks=12, c_hidden=384, c_latent=4, cod
 VQ["1b"] = VQ["570m"]
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2_f32, dense
 # SURVEY.md section 8(d), per image: 2 * steps * F_fwd(model, grid, S=4) + VQGAN f8 decode, in GFLOP (the GEMM-shaped work)
+WORKLOAD_TAG = {("570m", 1, 32, 8): "BASELINE configs[1]", ("570m", 64, 64, 12): "BASELINE configs[2]"}
 ALGO_GFLOP_PER_IMAGE = {("570m", 32, 8): 2 * 8 * 66.27 + 38.8}
 PEAK_HBM_GBS = 8000.0
 
@@ -248,7 +249,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
             "single_image_ms": round(ms_per_step / a.batch, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic (seeded random-init weights, random CLIP-text embeddings)",
-            "config": {"workload": "BASELINE configs[1]: Paella 573M-class (stand-in blocks=[4,8,4], %.1fM params), %dx%d tokens = %d px, "
+            "config": {"workload": WORKLOAD_TAG.get((a.model, a.batch, a.grid, a.sample_steps), "custom") + ": Paella 573M-class (stand-in blocks=[4,8,4], %.1fM params), %dx%d tokens = %d px, "
                                    "%d steps, CFG 8.0, CLIP-H-text only (S=4), batch %d per GPU, + VQGAN f8 decode"
                                    % (n_params / 1e6, a.grid, a.grid, a.grid * 8, a.sample_steps, a.batch),
                        "model": a.model, "batch_per_gpu": a.batch, "global_batch": total, "grid": a.grid, "sample_steps": a.sample_steps,

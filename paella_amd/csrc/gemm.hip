@@ -568,7 +568,7 @@ static void choose_config(int M, int N, int K, size_t ws_bytes, int* cfg_out, in
     const int ktiles = (K + 31) / 32;
     int cfg, S = 1;
     const double macs = (double)M * N * K;
-    if (tiles_of(0) >= 1024 && K <= 512) {
+    if (tiles_of(0) >= 2048 || (tiles_of(0) >= 1024 && K <= 512)) {  // >= 8 workgroups of 128x128 per CU: the big tile wins at any K (120-128 TF)
         cfg = 0;
     } else if (tiles_of(2) >= 1024 || macs >= 3e9) {  // big problems: 64x64 tiles, split only to reach ~1024 workgroups
         cfg = 2;
