@@ -103,8 +103,9 @@ int paella_unet_r_embedding(paella_unet* m, const float* r, int B, float max_pos
 int paella_unet_forward(paella_unet* m, const int64_t* tokens, const float* r, const void* cond, int B, int H, int W,
                         int S, const float* attn_weights, int n_attn_weights, float* logits_out, void* ws,
                         size_t ws_bytes, void* stream);
-/* The same evaluation when rows b and b + n_unique carry IDENTICAL tokens and r (classifier-free guidance: the conditional
- * and unconditional passes of src/utils.py:44-46 batched as 2 x n_unique rows).  The blocks ahead of the first attention
+/* The same evaluation when batch rows b, b + n_unique, ... share tokens and r (classifier-free guidance: the conditional
+ * and unconditional passes of src/utils.py:44-46 batched as 2 x n_unique rows against a B-row conditioning cache).
+ * tokens is int64 [n_unique,H,W] and r fp32 [n_unique]: only the distinct rows are passed.  The blocks ahead of the first attention
  * block never see the conditioning and are computed once for the n_unique distinct rows.  n_unique must divide B;
  * n_unique == B with mix_c == mix_u == 0 is paella_unet_forward.
  * (mix_c, mix_u) != (0, 0) (needs B == 2 * n_unique) additionally folds the guidance mix of src/utils.py:47 through the

@@ -123,8 +123,9 @@ int launch_embed_ln_unshuffle(const int64_t* tokens, const float* table, float* 
 
 // Sinusoidal timestep embedding + every TimestepBlock mapper in one launch.
 // r [B], freqs [c_r/2] (host-computed, torch order), Wcat [total, c_r], bcat [total] -> ts [B, total].
+// reps > 1: r holds B distinct samples and ts rows b, b + B, ... (reps of them) receive the same values
 int launch_timestep(const float* r, const float* freqs, const float* Wcat, const float* bcat, float* ts,
-                    int B, int c_r, int total, float max_positions, float* r_embed_out, hipStream_t stream);
+                    int B, int c_r, int total, float max_positions, float* r_embed_out, int reps, hipStream_t stream);
 // x = x*(1+a)+b with [a|b] = ts[b][0:2C] (standalone TimestepBlock).
 int launch_scale_shift(float* x, const float* ts, int ts_stride, int64_t rows, int rows_per_sample, int C,
                        hipStream_t stream);

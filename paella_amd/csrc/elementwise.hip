@@ -350,7 +350,7 @@ int launch_embed_ln_unshuffle(const int64_t* tokens, const float* table, float* 
 __global__ __launch_bounds__(256) void timestep_kernel(const float* __restrict__ r, const float* __restrict__ freqs,
                                                        const float* __restrict__ Wcat, const float* __restrict__ bcat,
                                                        float* __restrict__ ts, int c_r, int total, float max_positions,
-                                                       float* __restrict__ r_embed_out) {
+                                                       float* __restrict__ r_embed_out, int reps, int n_distinct) {
     extern __shared__ float emb[];
     const int b = blockIdx.y;
     const int half = c_r >> 1;
@@ -368,16 +368,17 @@ __global__ __launch_bounds__(256) void timestep_kernel(const float* __restrict__
     const float* w = Wcat + (size_t)o * c_r;
     float acc = 0.f;
     for (int k = 0; k < c_r; ++k) acc += emb[k] * w[k];
-    ts[(size_t)b * total + o] = acc + bcat[o];
+    const float out = acc + bcat[o];
+    for (int rep = 0; rep < reps; ++rep) ts[((size_t)rep * n_distinct + b) * total + o] = out;  // samples b, b + n_distinct, ... share r
 }
 
 int launch_timestep(const float* r, const float* freqs, const float* Wcat, const float* bcat, float* ts, int B,
-                    int c_r, int total, float max_positions, float* r_embed_out, hipStream_t st) {
+                    int c_r, int total, float max_positions, float* r_embed_out, int reps, hipStream_t st) {
     if (B <= 0) return PAELLA_OK;
     int gx = (total + 255) / 256;
     if (gx < 1) gx = 1;
     hipLaunchKernelGGL(timestep_kernel, dim3(gx, B), dim3(256), c_r * sizeof(float), st, r, freqs, Wcat, bcat, ts, c_r,
-                       total, max_positions, r_embed_out);
+                       total, max_positions, r_embed_out, reps < 1 ? 1 : reps, B);
     LAUNCH_CHECK_RET();
     return PAELLA_OK;
 }

@@ -365,9 +365,12 @@ extern "C" int paella_unet_set_timestep_freqs(paella_unet* m, const float* host_
     return PAELLA_OK;
 }
 
+int gemm_tile_counters(unsigned** out);  // gemm.hip
+
 extern "C" int paella_unet_finalize(paella_unet* m, void* stream) {
     (void)stream;
     if (!m) { paella_set_error("null argument"); return PAELLA_ERR_ARG; }
+    { unsigned* ctr = nullptr; RET_IF(gemm_tile_counters(&ctr)); }  // allocate the split-K tickets now: a first forward may run under stream capture
     for (auto& kv : m->specs) {
         auto it = m->t.find(kv.first);
         if (it == m->t.end() || !it->second.loaded) { paella_set_error("tensor '%s' was never loaded", kv.first.c_str()); return PAELLA_ERR_STATE; }
@@ -502,7 +505,7 @@ extern "C" int paella_unet_c_embeddings(paella_unet* m, const float* byt5, int S
 extern "C" int paella_unet_r_embedding(paella_unet* m, const float* r, int B, float max_positions, float* r_embed_out, void* stream) {
     if (!m || !m->finalized) { paella_set_error("model not finalized"); return PAELLA_ERR_STATE; }
     if (!r || !r_embed_out) { paella_set_error("null argument"); return PAELLA_ERR_ARG; }
-    return launch_timestep(r, m->freqs.p, m->ts_w.p, m->ts_b.p, nullptr, B, m->cfg.c_r, 0, max_positions, r_embed_out, (hipStream_t)stream);
+    return launch_timestep(r, m->freqs.p, m->ts_w.p, m->ts_b.p, nullptr, B, m->cfg.c_r, 0, max_positions, r_embed_out, 1, (hipStream_t)stream);
 }
 
 extern "C" int paella_unet_cond_prepare(paella_unet* m, const float* byt5, int S_byt5, const float* clip,
@@ -636,8 +639,8 @@ extern "C" int paella_unet_forward(paella_unet* m, const int64_t* tokens, const 
 }
 
 // Classifier-free guidance evaluates the SAME tokens and timestep against two conditionings (reference src/utils.py:44-46).
-// Everything before the first attention block never sees the conditioning, so with n_unique < B (rows b and b + n_unique carry
-// identical tokens / r) that prefix -- embedding, level-0 ResBlocks, the first down-sampler and ResBlock of level 1 -- is computed
+// Everything before the first attention block never sees the conditioning, so with n_unique < B (tokens [n_unique,H,W] and
+// r [n_unique] hold the distinct rows; batch rows b, b + n_unique, ... of `cond` share them) that prefix -- embedding, level-0 ResBlocks, the first down-sampler and ResBlock of level 1 -- is computed
 // for the n_unique distinct rows only and replicated (activations, saved skips, LayerNorm statistics) where the paths diverge.
 // The guidance mix l = mix_c * l_cond + mix_u * l_uncond (src/utils.py:47) can ride through the bias-free linear head
 // (out_mapper, src/modules.py:184-187): with (mix_c, mix_u) != (0, 0) and B == 2 * n_unique the head runs once on
@@ -670,11 +673,14 @@ extern "C" int paella_unet_forward_shared(paella_unet* m, const int64_t* tokens,
     const bool mix = mix_c != 0.f || mix_u != 0.f;
     if (mix && B != 2 * n_unique) { paella_set_error("guidance mix needs B == 2 * n_unique"); return PAELLA_ERR_ARG; }
     const int Bfull = B;
-    if (split > 0 && n_unique < B) { B = n_unique; cx.B = n_unique; }  // shared prefix on the distinct rows only
+    if (n_unique < B) {  // tokens / r hold the n_unique distinct rows: the prefix runs on them only
+        if (split < 0) split = 0;  // no attention on the way down: replicate right after the embedding
+        B = n_unique; cx.B = n_unique;
+    }
 
     // timestep embedding + all TimestepBlock mappers
     if (m->ts_total > 0)
-        RET_IF(launch_timestep(r, m->freqs.p, m->ts_w.p, m->ts_b.p, f.ts, Bfull, c.c_r, m->ts_total, 10000.0f, f.remb, st));
+        RET_IF(launch_timestep(r, m->freqs.p, m->ts_w.p, m->ts_b.p, f.ts, B, c.c_r, m->ts_total, 10000.0f, f.remb, Bfull / B, st));
 
     // in_mapper + PixelUnshuffle + embedding conv + LayerNorm2d   (src/modules.py:126-134,271)
     const int h0 = H / p, w0 = W / p;
@@ -730,6 +736,7 @@ extern "C" int paella_unet_forward_shared(paella_unet* m, const int64_t* tokens,
             default: break;
         }
     }
+    if (B != Bfull) { paella_set_error("internal: shared prefix never diverged"); return PAELLA_ERR_STATE; }
     // ---- up ---- (x continues in place on the deepest level's buffer)
     for (const Block& b : m->up) {
         switch (b.type) {

@@ -303,12 +303,13 @@ class Paella(nn.Module):
         return out
 
     # ------------------------------------------------------------------ forward
-    def forward_prepared(self, x, r, cond, attn_weights=None, out=None, n_unique=None, cfg_mix=None):
-        """One denoising evaluation against a `CondCache`. x int64 [B,H,W]; r fp32 [B].
-        n_unique < B promises that rows b and b + n_unique hold identical tokens and r (classifier-free guidance batches
-        the conditional and unconditional pass that way): the conditioning-independent prefix is then computed once.
-        cfg_mix=(a, b) with B == 2*n_unique folds the guidance mix a*logits[:B/2] + b*logits[B/2:] (src/utils.py:47) through
-        the bias-free linear head and returns only those B/2 mixed rows.
+    def forward_prepared(self, x, r, cond, attn_weights=None, out=None, cfg_mix=None):
+        """One denoising evaluation against a `CondCache`. x int64 [Bx,H,W]; r fp32 [Bx].
+        Normally Bx == cond.B.  With Bx < cond.B (cond.B a multiple of Bx) the rows b, b + Bx, ... of the conditioning
+        share the tokens and timestep of row b -- classifier-free guidance batches the conditional and unconditional pass
+        that way -- and the conditioning-independent prefix of the network is computed once for the Bx distinct rows.
+        cfg_mix=(a, b) with cond.B == 2*Bx additionally folds the guidance mix a*logits[:Bx] + b*logits[Bx:]
+        (src/utils.py:47) through the bias-free linear head and returns only those Bx mixed rows.
         Returns logits with the reference's shape [B, num_labels, H, W] (a channels-last view of the
         position-major buffer the kernels write; pass `out` = a [B,H,W,num_labels] fp32 tensor to reuse memory)."""
         h = self._engine()
@@ -317,21 +318,19 @@ class Paella(nn.Module):
         if not x.is_cuda or x.dtype != torch.int64 or x.dim() != 3:
             raise ValueError("x must be an int64 HIP tensor [B, H, W]")
         x = x.contiguous()
-        B, H, W = x.shape
+        nu, H, W = x.shape
         r = self._f32(r, "r")
-        if r.numel() != B:
+        if r.numel() != nu:
             raise ValueError("r must have one entry per sample")
-        if cond.B != B:
-            raise ValueError("conditioning batch %d != token batch %d" % (cond.B, B))
+        B = cond.B
+        if nu <= 0 or B % nu:
+            raise ValueError("conditioning batch %d is not a multiple of the token batch %d" % (B, nu))
         aw = self._f32(attn_weights, "attn_weights")
         if aw is not None and aw.dim() != 1:
             raise ValueError("attn_weights must be 1-D (utils/alter_attention.py:27)")
-        nu = B if n_unique is None else int(n_unique)
-        if nu <= 0 or B % nu:
-            raise ValueError("n_unique must divide the batch")
         mix = (0.0, 0.0) if cfg_mix is None else (float(cfg_mix[0]), float(cfg_mix[1]))
         if cfg_mix is not None and (B != 2 * nu or mix == (0.0, 0.0)):
-            raise ValueError("cfg_mix needs B == 2 * n_unique and a non-zero mix")
+            raise ValueError("cfg_mix needs a conditioning batch of twice the token batch and a non-zero mix")
         Bo = nu if cfg_mix is not None else B
         if out is None:
             out = torch.empty(Bo, H, W, self.num_labels, dtype=torch.float32, device=dev)

@@ -70,10 +70,16 @@ def _tail(logits_c, logits_u, rows, L, cfg, omc, temperature, mode, noise_q, see
                                              _lib.ptr(mask_u), t_next, _lib.ptr(out), None, _lib.stream_ptr(dev)))
 
 
+def timestep_table(t_list, steps, B, device):
+    """[steps, B] fp32: row i = the timestep of step i for every sample (one upload instead of a fill kernel per step)."""
+    return torch.tensor([float(v) for v in t_list[:steps]], dtype=torch.float32).to(device)[:, None].repeat(1, B).contiguous()
+
+
 def _sample_core(model, model_inputs, unconditional_inputs, latent_shape, init_x, steps, renoise_steps, t_list, temperatures,
-                 cfgs, device, noise="torch", seed=0, attn_weights=None, seed_dev=None, init_noise_buf=None):
+                 cfgs, device, noise="torch", seed=0, attn_weights=None, seed_dev=None, init_noise_buf=None, r_all=None):
     """cfgs: per-step list of (cfg_fp32, one_minus_cfg_fp32) or None (no guidance at that step).
-    seed_dev / init_noise_buf: device-resident seed word and pre-drawn start tokens (HIP-graph capture, see GraphSampler)."""
+    seed_dev / init_noise_buf / r_all: device-resident seed word, pre-drawn start tokens and the [steps, B] timestep table
+    (HIP-graph capture cannot upload from the host, see GraphSampler)."""
     explicit = isinstance(noise, dict)  # parity tests: {"init_noise": [B,H,W], "q": [rows,L] per step, "u": [B,H,W] per step}
     if not explicit and noise not in ("torch", "philox"):
         raise ValueError("noise must be 'torch', 'philox' or a dict of explicit noise tensors")
@@ -106,17 +112,20 @@ def _sample_core(model, model_inputs, unconditional_inputs, latent_shape, init_x
             logits_c = torch.empty(B, H, W, L, dtype=torch.float32, device=device)
             logits_u = torch.empty(B, H, W, L, dtype=torch.float32, device=device) if any_cfg and not batched else None
         out = torch.empty(B, H, W, dtype=torch.int64, device=device)
+        if r_all is None:
+            r_all = timestep_table(t_list, steps, B, device)
         for i in range(steps):
-            r = torch.full((B,), t_list[i], dtype=torch.float32, device=device)
+            r = r_all[i]
             use_cfg = cfgs[i] is not None
             if native:
                 if use_cfg and batched:
-                    # both halves hold the same tokens / r: the library computes the conditioning-free prefix once.
-                    # With the counter-based generator (no bit-parity promise towards torch's RNG stream) a categorical
-                    # step also lets the guidance mix ride through the linear head: one mixed logits tensor comes back.
+                    # one evaluation against the 2B-row conditioning cache: tokens / r are passed once, the library computes
+                    # the conditioning-free prefix for them and replicates it where the two passes diverge.  With the
+                    # counter-based generator (no bit-parity promise towards torch's RNG stream) a categorical step also lets
+                    # the guidance mix ride through the linear head: one mixed logits tensor comes back.
                     fold = (not explicit) and noise == "philox" and temperatures[i] != 0
-                    model.forward_prepared(torch.cat([sampled, sampled], dim=0), torch.cat([r, r]), cond_both, attn_weights=attn_weights,
-                                           out=logits2[:B] if fold else logits2, n_unique=B, cfg_mix=cfgs[i] if fold else None)
+                    model.forward_prepared(sampled, r, cond_both, attn_weights=attn_weights, out=logits2[:B] if fold else logits2,
+                                           cfg_mix=cfgs[i] if fold else None)
                     lc, lu = logits2[:B], (None if fold else logits2[B:])
                 else:
                     model.forward_prepared(sampled, r, cond_c, attn_weights=attn_weights, out=logits_c)
@@ -214,6 +223,7 @@ class GraphSampler:
         self.cond, self.uncond = clone(model_inputs), clone(unconditional_inputs)
         self.seed_dev = torch.zeros(1, dtype=torch.int64, device=self.device)
         self.init_noise = torch.zeros(self.shape, dtype=torch.int64, device=self.device)
+        self.r_all = timestep_table(linspace_schedule(t_start, t_end, steps + 1), steps, self.shape[0], self.device)
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):
@@ -238,7 +248,7 @@ class GraphSampler:
             cfgs = [None] * k["steps"]
         toks = _sample_core(self.model, self.cond, self.uncond, self.shape, None, k["steps"], k["renoise_steps"], t_list, temps, cfgs,
                             self.device, noise="philox", seed=0, attn_weights=self.attn_weights, seed_dev=self.seed_dev,
-                            init_noise_buf=self.init_noise)
+                            init_noise_buf=self.init_noise, r_all=self.r_all)
         return toks if self.vqgan is None else (toks, self.vqgan.decode_indices(toks))
 
     @staticmethod
