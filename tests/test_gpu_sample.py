@@ -199,3 +199,30 @@ def test_config3_full_size_step_properties(built_lib):
     logits = m(x, r, **c2)
     assert torch.isfinite(logits).all()
     torch.cuda.empty_cache()
+
+
+def test_config4_full_size_step_properties(built_lib):
+    """BASELINE configs[3] per-GPU share at FULL size: released-size 1B model, ByT5 (768 tokens) + CLIP text + CLIP image
+    conditioning, 64x64 tokens, batch 32 per GPU.  The unconditional set has a different (short) ByT5 length, so the two
+    guidance passes cannot be batched and run as separate forwards (the other CFG code path).  One argmax step:
+    tokens in range, deterministic, and a 2-row shard reproduces the same rows of the full batch up to near-tie flips."""
+    cfg = G.UNET_1B
+    m = paella_amd.Paella(**cfg)
+    weights_for(m, sum(cfg["blocks"]))
+    m = m.to(DEV)
+    B, H = 32, 64
+    L = cfg["num_labels"]
+    cs, us = to_dev(cond_for(cfg, B, 768, 1, 51), DEV), to_dev(cond_for(cfg, B, 2, 1, 52), DEV)
+    g = torch.Generator().manual_seed(10)
+    init = torch.randint(0, L, (B, H, H), generator=g)
+    u = torch.rand(B, H, H, generator=g)
+    run = lambda c, un, lo, hi: paella_amd.sample(m, c, (hi - lo, H, H), unconditional_inputs=un, steps=1, renoise_steps=1, temperature=(0.0, 0.0),
+                                                  cfg=8.0, device=DEV, noise={"init_noise": init[lo:hi], "q": [None], "u": [u[lo:hi]]})
+    full = run(cs, us, 0, B)
+    assert full.shape == (B, H, H) and int(full.min()) >= 0 and int(full.max()) < L
+    assert torch.equal(full, run(cs, us, 0, B))
+    from paella_amd.dist import shard_inputs
+    part = run(shard_inputs(cs, 30, 32), shard_inputs(us, 30, 32), 30, 32)
+    same = (part == full[30:32]).float().mean().item()
+    assert same >= 0.999, same
+    torch.cuda.empty_cache()
