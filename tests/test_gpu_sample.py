@@ -226,3 +226,31 @@ def test_config4_full_size_step_properties(built_lib):
     same = (part == full[30:32]).float().mean().item()
     assert same >= 0.999, same
     torch.cuda.empty_cache()
+
+
+def test_config5_full_size_inpaint_properties(built_lib):
+    """BASELINE configs[4] per-GPU share at FULL size: 1B model, 1024x1024 px = 128x128 tokens (VQGAN f8), batch 16 per GPU:
+    VQGAN encode -> masked renoise -> sample(init_x, t_start < 1) -> decode.  Properties: shapes, token range, the known
+    region is preserved and the hole is regenerated."""
+    cfg = G.UNET_1B
+    m = paella_amd.Paella(**cfg)
+    weights_for(m, sum(cfg["blocks"]))
+    m = m.to(DEV)
+    vq = paella_amd.VQModel(levels=3)
+    weights_for(vq, 2)
+    vq = vq.to(DEV)
+    B, P = 16, 1024
+    g = torch.Generator().manual_seed(12)
+    img = torch.rand(B, 3, P, P, generator=g).to(DEV)
+    cs, us = to_dev(cond_for(cfg, B, 256, 1, 61), DEV), to_dev(cond_for(cfg, B, 256, 1, 62), DEV)
+    mask = torch.zeros(B, 128, 128, dtype=torch.int64)
+    mask[:, 32:96, 40:100] = 1
+    torch.manual_seed(3)
+    toks, out = paella_amd.inpaint(m, vq, img, mask, cs, us, steps=2, t_start=0.5, noise="philox", seed=5)
+    orig = vq.encode(img)[2]
+    assert toks.shape == (B, 128, 128) and out.shape == img.shape and torch.isfinite(out).all()
+    assert int(toks.min()) >= 0 and int(toks.max()) < cfg["num_labels"]
+    mk = mask.to(DEV).bool()
+    assert torch.equal(toks[~mk], orig[~mk])
+    assert (toks[mk] != orig[mk]).float().mean() > 0.2
+    torch.cuda.empty_cache()
