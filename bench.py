@@ -41,6 +41,7 @@ VQ = {"570m": dict(levels=3, bottleneck_blocks=12, c_hidden=384, c_latent=4, cod
 VQ["1b"] = VQ["570m"]
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2_f32, dense
 # SURVEY.md section 8(d), per image: 2 * steps * F_fwd(model, grid, S=4) + VQGAN f8 decode, in GFLOP (the GEMM-shaped work)
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA (v_mfma_f32_16x16x32_bf16), MI355X_MICROARCH.md
 WORKLOAD_TAG = {("570m", 1, 32, 8): "BASELINE configs[1]", ("570m", 64, 64, 12): "BASELINE configs[2]"}
 ALGO_GFLOP_PER_IMAGE = {("570m", 32, 8): 2 * 8 * 66.27 + 38.8}
 PEAK_HBM_GBS = 8000.0
@@ -60,6 +61,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the informational batched-throughput run")
     ap.add_argument("--extra-batch", type=int, default=8)
+    ap.add_argument("--gemm", default="fp32", choices=["fp32", "bf16"],
+                    help="fp32 = the exact path (the headline); bf16 = OPT-IN fast mode outside the parity contract (bf16 MFMA operands, fp32 accumulate)")
     ap.add_argument("--force-dist", action="store_true", help="take the torch.distributed (RCCL) path even at world size 1 (launch under torchrun)")
     return ap.parse_args()
 
@@ -130,6 +133,7 @@ def main():
     from paella_amd import _lib, synth
     from paella_amd.dist import broadcast_conditioning, shard_bounds, shard_inputs
     lib = _lib.load()  # fails loudly if the HIP library is missing
+    paella_amd.set_gemm_precision(a.gemm)
 
     mcfg, vcfg = MODELS[a.model], VQ[a.model]
     model = paella_amd.Paella(**mcfg)
@@ -201,14 +205,16 @@ def main():
         # + one VQGAN decode.  The CFG de-duplication executes fewer FLOPs for the same result, so both
         # figures are reported: `achieved` prices the algorithmic work, `executed_tflops` what the launches really multiplied.
         algo = ALGO_GFLOP_PER_IMAGE.get((a.model, a.grid, a.sample_steps))
+        peak = PEAK_FP32_MFMA_TFLOPS if a.gemm == "fp32" else PEAK_BF16_MFMA_TFLOPS
         executed = ach
         if algo is not None and ms.value > 0:
             ach = algo * a.batch * 1e9 / (ms.value * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "gemm_nt_kernel (fp32 v_mfma_f32_16x16x4_f32, all tile configs, split-K reduce included)",
-                "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+        roof = {"bound": "mfma", "kernel": ("gemm_nt_kernel (fp32 v_mfma_f32_16x16x4_f32, all tile configs, split-K reduce included)" if a.gemm == "fp32"
+                                            else "gemm_bf16_kernel (v_mfma_f32_16x16x32_bf16) + fp32 gemm_nt_kernel for the few GEMMs without a bf16 path"),
+                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                 "achieved_basis": ("SURVEY 8(d) algorithmic GFLOP per image (2 x steps full forwards + decode) / summed GEMM launch time"
                                    if algo is not None else "executed GEMM FLOPs / summed GEMM launch time"),
-                "executed_tflops": round(executed, 2), "executed_frac": round(executed / PEAK_FP32_MFMA_TFLOPS, 4),
+                "executed_tflops": round(executed, 2), "executed_frac": round(executed / peak, 4),
                 "algorithmic_gflop_per_image": algo,
                 "traffic": traffic, "traffic_source": traffic_note, "algorithmic_bytes_per_launch": round(by.value / max(n.value, 1)),
                 "launches_per_step": int(n.value), "avg_launch_us": round(ms.value * 1e3 / max(n.value, 1), 2),
@@ -248,7 +254,7 @@ def main():
             "metric": "images/sec (whole node) + single-image ms, 256x256 @ 8 steps", "value": round(value, 4), "unit": "images/sec",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
             "single_image_ms": round(ms_per_step / a.batch, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic (seeded random-init weights, random CLIP-text embeddings)",
+            "dtype": "f32" if a.gemm == "fp32" else "bf16 MFMA operands / f32 accumulate and f32 everywhere else (opt-in fast mode, outside the parity contract)", "data": "synthetic (seeded random-init weights, random CLIP-text embeddings)",
             "config": {"workload": WORKLOAD_TAG.get((a.model, a.batch, a.grid, a.sample_steps), "custom") + ": Paella 573M-class (stand-in blocks=[4,8,4], %.1fM params), %dx%d tokens = %d px, "
                                    "%d steps, CFG 8.0, CLIP-H-text only (S=4), batch %d per GPU, + VQGAN f8 decode"
                                    % (n_params / 1e6, a.grid, a.grid, a.grid * 8, a.sample_steps, a.batch),

@@ -97,6 +97,13 @@ int paella_unet_c_embeddings(paella_unet* m, const float* byt5, int S_byt5, cons
 int paella_unet_r_embedding(paella_unet* m, const float* r, int B, float max_positions, float* r_embed_out,
                             void* stream);
 
+/* OPT-IN fast mode, outside the fp32 parity contract: mode 1 routes every dense contraction whose weight the library owns
+ * through bf16-operand MFMA (v_mfma_f32_16x16x32_bf16, fp32 accumulation; activations rounded to bf16 on the way into
+ * the matrix cores, weights from a bf16 shadow copy made at finalize).  Mode 0 (default) is the exact fp32 path.
+ * Process-wide; returns PAELLA_OK. */
+int paella_set_gemm_precision(int mode);
+int paella_get_gemm_precision(void);
+
 /* One denoising evaluation = Paella.forward (src/modules.py:263-275) with the conditioning already prepared.
  * tokens int64 [B,H,W]; r fp32 [B]; attn_weights (utils/alter_attention.py:23-34) fp32 [n_attn_weights] or NULL;
  * logits_out fp32 [B,H,W,num_labels]. */
@@ -201,6 +208,8 @@ int paella_prof_collect(double* total_ms, double* total_flops, double* total_byt
 int paella_debug_launch_chain(float* buf, int n_elems, int blocks, int n_launches, void* stream);
 /* A/B switch for the GEMM workgroup-spreading LDS reservation (default on) */
 int paella_debug_set_spread(int on);
+/* Test hook: (un)register an arbitrary fp32 [N,K] matrix for the bf16 fast mode so paella_op_gemm(tile_cfg 96..98) can use it. */
+int paella_debug_register_weight(const float* w, size_t numel, int on);
 /* Timeline probe (tools/gemm_timeline.py): device buffer of 8 x uint64 per workgroup that the probe build of the GEMM
  * (tile config 128 + tile) fills with 100 MHz wall-clock stamps; NULL switches it off. */
 int paella_debug_set_trace(void* dev_buf);

@@ -13,5 +13,21 @@ from .modules import CondCache, DenoiseUNet, Paella, replace_attention_layers
 from .sampling import GraphSampler, sample, sample_distributed
 from .vqgan import VectorQuantize, VQModel
 
-__all__ = ["Paella", "DenoiseUNet", "CondCache", "VQModel", "VectorQuantize", "sample", "sample_distributed", "GraphSampler",
+
+def set_gemm_precision(mode):
+    """OPT-IN fast mode, outside the fp32 parity contract: "bf16" sends every dense contraction through bf16-operand MFMA
+    with fp32 accumulation (weights from a bf16 shadow copy, activations rounded on the way into the matrix cores);
+    "fp32" (default) is the exact path.  Process-wide."""
+    from . import _lib
+    modes = {"fp32": 0, "f32": 0, "bf16": 1}
+    if mode not in modes:
+        raise ValueError("gemm precision must be 'fp32' or 'bf16'")
+    _lib.check(_lib.load().paella_set_gemm_precision(modes[mode]))
+
+
+def get_gemm_precision():
+    from . import _lib
+    return "bf16" if _lib.load().paella_get_gemm_precision() == 1 else "fp32"
+
+__all__ = ["Paella", "DenoiseUNet", "CondCache", "VQModel", "VectorQuantize", "sample", "sample_distributed", "GraphSampler", "set_gemm_precision", "get_gemm_precision",
            "replace_attention_layers", "inpaint"]

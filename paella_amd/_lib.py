@@ -73,6 +73,9 @@ SIGNATURES = {
     "paella_prof_enable": (c_int, [c_int]),
     "paella_prof_collect": (c_int, [POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int64)]),
     "paella_debug_set_spread": (c_int, [c_int]),
+    "paella_debug_register_weight": (c_int, [c_void_p, c_size_t, c_int]),
+    "paella_set_gemm_precision": (c_int, [c_int]),
+    "paella_get_gemm_precision": (c_int, []),
     "paella_debug_set_trace": (c_int, [c_void_p]),
     "paella_debug_launch_chain": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     "paella_op_gemm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,

@@ -668,6 +668,11 @@ static int launch_gemm_cfg_impl(const GemmArgs& g, int cfg, int splitk, void* ws
         paella_set_error("gemm: depth-to-space store needs channels %% 4 == 0");
         return PAELLA_ERR_ARG;
     }
+    if (cfg >= 96 && cfg < 99) return launch_gemm_bf16(g, cfg - 96, splitk, ws, ws_bytes, st);  // explicit bf16 tile (tests / tools)
+    if (cfg < 0 && gemm_precision() == 1) {  // opt-in fast mode: bf16 operands where a shadow weight exists
+        const int rc = launch_gemm_bf16(g, -1, 1, ws, ws_bytes, st);
+        if (rc != PAELLA_ERR_STATE) return rc;
+    }
     int S = splitk;
     if (cfg < 0) choose_config(g.M, g.N, g.K, ws ? ws_bytes : 0, &cfg, &S);
     if (cfg >= 16 && cfg < 25) return launch_gemm_ws(g, (cfg - 16) / 3, (cfg - 16) % 3, S, ws, ws_bytes, st);

@@ -263,7 +263,7 @@ extern "C" int paella_unet_create(const paella_unet_config* cfg, paella_unet** o
 
 extern "C" void paella_unet_destroy(paella_unet* m) {
     if (!m) return;
-    for (auto& kv : m->t) if (kv.second.p) (void)hipFree(kv.second.p);
+    for (auto& kv : m->t) if (kv.second.p) { gemm_unregister_weight(kv.second.p); (void)hipFree(kv.second.p); }
     if (m->ts_w.p) (void)hipFree(m->ts_w.p);
     if (m->ts_b.p) (void)hipFree(m->ts_b.p);
     if (m->freqs.p) (void)hipFree(m->freqs.p);
@@ -371,6 +371,8 @@ extern "C" int paella_unet_finalize(paella_unet* m, void* stream) {
     (void)stream;
     if (!m) { paella_set_error("null argument"); return PAELLA_ERR_ARG; }
     { unsigned* ctr = nullptr; RET_IF(gemm_tile_counters(&ctr)); }  // allocate the split-K tickets now: a first forward may run under stream capture
+    for (auto& kv : m->t)  // bf16 shadow copies for the opt-in fast mode are (re)made from the tensors as loaded now
+        if (kv.second.p && kv.second.n >= 4096) RET_IF(gemm_register_weight(kv.second.p, kv.second.n));
     for (auto& kv : m->specs) {
         auto it = m->t.find(kv.first);
         if (it == m->t.end() || !it->second.loaded) { paella_set_error("tensor '%s' was never loaded", kv.first.c_str()); return PAELLA_ERR_STATE; }
@@ -825,6 +827,11 @@ extern "C" int paella_op_gemm(const float* A, const float* W, const float* bias,
     GemmArgs g = gemm_args(A, K, W, K, C, N, M, N, K);
     g.ep.bias = bias; g.ep.act = act; g.ep.residual = residual; g.ep.ldr = N;
     return launch_gemm_cfg(g, tile_cfg, splitk, ws, ws_bytes, (hipStream_t)stream);
+}
+extern "C" int paella_debug_register_weight(const float* w, size_t numel, int on) {
+    if (on) return gemm_register_weight(w, numel);
+    gemm_unregister_weight(w);
+    return PAELLA_OK;
 }
 extern "C" int paella_op_layernorm(const float* x, float* y, int64_t rows, int C, float eps, void* stream) {
     return launch_layernorm(x, y, rows, C, eps, 1.f, 0.f, 0, 0, 0, (hipStream_t)stream);
