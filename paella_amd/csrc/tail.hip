@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void sample_tail_kernel(TailArgs a) {
                 uint32_t rb[4];
                 philox4x32(seed, (uint64_t)row * L4 + i4, a.offset, rb);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) q[e] = -logf(u01_open(rb[e]));
+                for (int e = 0; e < 4; ++e) q[e] = __logf(-logf(u01_open(rb[e])));  // log of an Exp(1) variate: argmax(p/q) == argmax(log p - log q)
             }
         }
 #pragma unroll
@@ -100,9 +100,12 @@ __global__ __launch_bounds__(256) void sample_tail_kernel(TailArgs a) {
             float score;
             if (argmax_mode) {
                 score = x;
-            } else {
+            } else if (nq) {  // parity mode: the reference's arithmetic, softmax numerator over Exp(1) noise
                 x = __fdiv_rn(x, a.temperature);
                 score = __fdiv_rn(expf(__fsub_rn(x, mx)), q[e]);
+            } else {          // counter-based noise: the same draw in the log domain (Gumbel-max), no exp and no second division
+                x = __fdiv_rn(x, a.temperature);
+                score = (x - mx) - q[e];
             }
             const int idx = i4 * 4 + e;
             if (score > best || (score == best && idx < best_i)) { best = score; best_i = idx; }
