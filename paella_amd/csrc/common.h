@@ -94,7 +94,7 @@ size_t gemm_splitk_ws_bytes(int M, int N, int K);
 // opt-in bf16-operand fast mode (gemm_bf16.hip).  launch_gemm_bf16 returns PAELLA_ERR_STATE when this GEMM has no bf16
 // shadow weight / unsuitable K: the caller falls back to the fp32 kernel.  tile: 0 = 128x128, 1 = 64x64, 2 = 32x32, -1 = choose.
 int launch_gemm_bf16(const GemmArgs& g, int tile, int splitk, void* ws, size_t ws_bytes, hipStream_t stream);
-int gemm_register_weight(const float* base, size_t numel);
+int gemm_register_weight(const float* base, size_t numel, hipStream_t stream);
 void gemm_unregister_weight(const float* base);
 int gemm_precision();
 // weight-streaming kernel (gemm_ws.hip): tm_code 0..2 -> BM = 16,32,64; nk_code 0..2 -> K-slice capacity 128,192,320; in-launch split-K reduce

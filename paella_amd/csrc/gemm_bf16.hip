@@ -247,25 +247,26 @@ struct ShadowEntry { size_t numel; unsigned short* b; bool dirty; };
 static std::map<const float*, ShadowEntry> g_shadow;  // keyed by the fp32 tensor's base address
 static int g_precision = 0;                            // 0 = exact fp32 (default), 1 = bf16 operands
 
-static int shadow_convert(const float* base, ShadowEntry& e) {
+// `st` = the stream the fp32 tensor was (re)written on; the copy is complete when this returns
+static int shadow_convert(const float* base, ShadowEntry& e, hipStream_t st) {
     if (!e.b) HIP_CHECK_RET(hipMalloc((void**)&e.b, e.numel * sizeof(unsigned short)));
     size_t blocks = (e.numel + 255) / 256;
     if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, 0, base, e.b, e.numel);
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, base, e.b, e.numel);
     LAUNCH_CHECK_RET();
-    HIP_CHECK_RET(hipStreamSynchronize(0));
+    HIP_CHECK_RET(hipStreamSynchronize(st));
     e.dirty = false;
     return PAELLA_OK;
 }
 
 // Models call this for every library-owned weight tensor at finalize (and again after a reload: the copy is refreshed).
-int gemm_register_weight(const float* base, size_t numel) {
+int gemm_register_weight(const float* base, size_t numel, hipStream_t st) {
     if (!base || numel == 0) return PAELLA_OK;
     ShadowEntry& e = g_shadow[base];
     if (e.b && e.numel != numel) { (void)hipFree(e.b); e.b = nullptr; }
     e.numel = numel;
     e.dirty = true;
-    return g_precision == 1 ? shadow_convert(base, e) : PAELLA_OK;
+    return g_precision == 1 ? shadow_convert(base, e, st) : PAELLA_OK;
 }
 
 void gemm_unregister_weight(const float* base) {
@@ -279,9 +280,11 @@ int gemm_precision() { return g_precision; }
 
 extern "C" int paella_set_gemm_precision(int mode) {
     if (mode != 0 && mode != 1) { paella_set_error("gemm precision mode must be 0 (fp32) or 1 (bf16 operands)"); return PAELLA_ERR_ARG; }
-    if (mode == 1)
+    if (mode == 1) {
+        HIP_CHECK_RET(hipDeviceSynchronize());  // weights may still be in flight on any stream
         for (auto& kv : g_shadow)
-            if (kv.second.dirty || !kv.second.b) { const int rc = shadow_convert(kv.first, kv.second); if (rc != PAELLA_OK) return rc; }
+            if (kv.second.dirty || !kv.second.b) { const int rc = shadow_convert(kv.first, kv.second, 0); if (rc != PAELLA_OK) return rc; }
+    }
     g_precision = mode;
     return PAELLA_OK;
 }

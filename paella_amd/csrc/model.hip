@@ -368,11 +368,10 @@ extern "C" int paella_unet_set_timestep_freqs(paella_unet* m, const float* host_
 int gemm_tile_counters(unsigned** out);  // gemm.hip
 
 extern "C" int paella_unet_finalize(paella_unet* m, void* stream) {
-    (void)stream;
     if (!m) { paella_set_error("null argument"); return PAELLA_ERR_ARG; }
     { unsigned* ctr = nullptr; RET_IF(gemm_tile_counters(&ctr)); }  // allocate the split-K tickets now: a first forward may run under stream capture
     for (auto& kv : m->t)  // bf16 shadow copies for the opt-in fast mode are (re)made from the tensors as loaded now
-        if (kv.second.p && kv.second.n >= 4096) RET_IF(gemm_register_weight(kv.second.p, kv.second.n));
+        if (kv.second.p && kv.second.n >= 4096) RET_IF(gemm_register_weight(kv.second.p, kv.second.n, (hipStream_t)stream));
     for (auto& kv : m->specs) {
         auto it = m->t.find(kv.first);
         if (it == m->t.end() || !it->second.loaded) { paella_set_error("tensor '%s' was never loaded", kv.first.c_str()); return PAELLA_ERR_STATE; }
@@ -829,7 +828,7 @@ extern "C" int paella_op_gemm(const float* A, const float* W, const float* bias,
     return launch_gemm_cfg(g, tile_cfg, splitk, ws, ws_bytes, (hipStream_t)stream);
 }
 extern "C" int paella_debug_register_weight(const float* w, size_t numel, int on) {
-    if (on) return gemm_register_weight(w, numel);
+    if (on) return gemm_register_weight(w, numel, 0);
     gemm_unregister_weight(w);
     return PAELLA_OK;
 }

@@ -205,10 +205,10 @@ extern "C" int paella_vqgan_finalize(paella_vqgan* v, void* stream) {
         }
     HIP_CHECK_RET(hipStreamSynchronize(st));
     for (auto& kv : v->t)  // bf16 shadow copies for the opt-in fast mode
-        if (kv.second.p && kv.second.n >= 4096) RET_IF(gemm_register_weight(kv.second.p, kv.second.n));
+        if (kv.second.p && kv.second.n >= 4096) RET_IF(gemm_register_weight(kv.second.p, kv.second.n, st));
     for (auto* seq : {&v->enc, &v->dec})
         for (auto& b : *seq)
-            for (auto& pw : b.phase_w) if (pw.p && pw.n >= 4096) RET_IF(gemm_register_weight(pw.p, pw.n));
+            for (auto& pw : b.phase_w) if (pw.p && pw.n >= 4096) RET_IF(gemm_register_weight(pw.p, pw.n, st));
     v->finalized = true;
     return PAELLA_OK;
 }

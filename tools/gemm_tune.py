@@ -30,6 +30,10 @@ SHAPES = {
     "c3 L1 mlp1 32768x5120x1280": (32768, 5120, 1280), "c3 L1 mlp2 32768x1280x5120": (32768, 1280, 5120),
     "c3 L1 qkv 32768x3840x1280": (32768, 3840, 1280), "c3 L2 mlp1 8192x5120x1280": (8192, 5120, 1280),
     "c3 head 262144x8192x256": (262144, 8192, 256),
+    # batch 32 at 32x32 tokens
+    "b32 L1 mlp1 4096x5120x1280": (4096, 5120, 1280), "b32 L1 mlp2 4096x1280x5120": (4096, 1280, 5120), "b32 L1 qkv 4096x3840x1280": (4096, 3840, 1280),
+    "b32 L1 out 4096x1280x1280": (4096, 1280, 1280), "b32 L0 mlp1 16384x2560x640": (16384, 2560, 640), "b32 L2 mlp1 1024x5120x1280": (1024, 5120, 1280),
+    "b32 L2 mlp2 1024x1280x5120": (1024, 1280, 5120),
     "b8 L0 mlp1 4096x2560x640": (4096, 2560, 640), "b8 L0 mlp2 4096x640x2560": (4096, 640, 2560),
     "b8 L1 mlp1 1024x5120x1280": (1024, 5120, 1280), "b8 L1 mlp2 1024x1280x5120": (1024, 1280, 5120),
     "b8 L2 mlp1 256x5120x1280": (256, 5120, 1280), "b8 L2 mlp2 256x1280x5120": (256, 1280, 5120),
@@ -54,13 +58,13 @@ def main():
         # cold weights without a flush kernel: rotate over enough distinct copies of W to exceed the 256 MiB MALL,
         # exactly like consecutive layers of the model; activations stay warm.  One event pair brackets a whole
         # rotation of back-to-back launches, so the figure includes the real launch boundaries.
-        ncopy = max(2, min(64, int(600e6 // (N * K * 4)) + 1)) if M < 8192 else 2
+        ncopy = max(2, min(64, int(600e6 // (N * K * 4)) + 1)) if M < 4096 else 3
         A = torch.randn(M, K, device="cuda")
         Ws = [torch.randn(N, K, device="cuda") for _ in range(ncopy)]
         C = torch.empty(M, N, device="cuda")
         row = {}
         variants = [(-1, 1)] + [(c, s) for c in range(9) for s in (1, 2, 4, 8, 16)] + [(c, s) for c in (34, 36, 37) for s in (1, 2, 4, 8, 16)]
-        if M >= 8192:  # MFMA-bound: no split-K, few candidates, few iterations
+        if M >= 4096:  # MFMA-bound: no split-K, few candidates, few iterations
             variants = [(-1, 1)] + [(c, 1) for c in (0, 1, 2, 3, 8, 34)]
         for cfg, sk in variants:
             if sk > 1 and (K // sk < 128 or sk * max(M, 128) * N * 4 > ws.numel()):
@@ -70,7 +74,7 @@ def main():
             if run(Ws[0]) != 0:
                 continue
             ts = []
-            for _ in range(max(3, a.iters // 6) if M < 8192 else 3):
+            for _ in range(max(3, a.iters // 6) if M < 4096 else 3):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for W in Ws:
@@ -89,7 +93,7 @@ def main():
                          "heuristic_us": heur, "heuristic_tflops": round(flops / heur / 1e6, 1) if heur else None,
                          "hbm_floor_us": round((M * K + N * K + M * N) * 4 / 6.3e6, 2), "mfma_floor_us": round(flops / 157.3e6, 2)}
         r = results[name]
-        print("%-34s all %s" % (name, " ".join("%s=%.0f" % kv for kv in row.items())) if M >= 8192 else "", end="\n" if M >= 8192 else "")
+        print("%-34s all %s" % (name, " ".join("%s=%.0f" % kv for kv in row.items())) if M >= 4096 else "", end="\n" if M >= 4096 else "")
         print("%-28s best %-6s %8.1f us %6.1f TF | heuristic %8.1f us %6.1f TF | best PD=1 %-6s %6.1f us | floors hbm %.1f mfma %.1f us" %
               (name, r["best"], r["best_us"], r["best_tflops"], heur, r["heuristic_tflops"], pd1[1], pd1[0], r["hbm_floor_us"], r["mfma_floor_us"]), flush=True)
     if a.out:
