@@ -641,8 +641,9 @@ extern "C" int paella_unet_forward(paella_unet* m, const int64_t* tokens, const 
 
 // Classifier-free guidance evaluates the SAME tokens and timestep against two conditionings (reference src/utils.py:44-46).
 // Everything before the first attention block never sees the conditioning, so with n_unique < B (tokens [n_unique,H,W] and
-// r [n_unique] hold the distinct rows; batch rows b, b + n_unique, ... of `cond` share them) that prefix -- embedding, level-0 ResBlocks, the first down-sampler and ResBlock of level 1 -- is computed
-// for the n_unique distinct rows only and replicated (activations, saved skips, LayerNorm statistics) where the paths diverge.
+// r [n_unique] hold the distinct rows; batch rows b, b + n_unique, ... of `cond` share them) that prefix -- embedding,
+// level-0 ResBlocks, the first down-sampler and ResBlock of level 1 -- is computed for the n_unique distinct rows only and
+// replicated (activations, saved skips, LayerNorm statistics) where the paths diverge.
 // The guidance mix l = mix_c * l_cond + mix_u * l_uncond (src/utils.py:47) can ride through the bias-free linear head
 // (out_mapper, src/modules.py:184-187): with (mix_c, mix_u) != (0, 0) and B == 2 * n_unique the head runs once on
 // mix_c * LN(z_cond) + mix_u * LN(z_uncond) and logits_out receives the n_unique MIXED rows (half the head FLOPs and logits bytes).
