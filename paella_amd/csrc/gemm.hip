@@ -35,11 +35,14 @@ __device__ unsigned long long* g_trace_ptr = nullptr;
     } while (0)
 
 template <int WM, int WN, int TM, int TN, int PD, int APRO, bool GLDS, int ABL = 0>  // APRO: 0 none, 1 GRN scale/shift, 2 LayerNorm from row statistics
-__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g, int kslice, int S, float* __restrict__ slabs,
-                                                      int tiles_m, int tiles_n, unsigned* __restrict__ counters, unsigned slab_bytes) {
+__global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs g, int kslice, int S, float* __restrict__ slabs,
+                                                               int tiles_m, int tiles_n, unsigned* __restrict__ counters, unsigned slab_bytes) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16, BK = 32;
-    constexpr int LA = (BM * 8 + 255) / 256, LB = (BN * 8 + 255) / 256;
-    static_assert(WM * WN == 4, "4 waves per workgroup");
+    constexpr int NW = WM * WN, NT = 64 * NW;  // 4 waves (256 threads), or 8 waves for the 128x128 tile with 64x32 wave tiles
+    constexpr int RP = NT / 8;                 // rows staged per pass: 8 threads (one float4 each) cover a 32-float row
+    constexpr int LA = (BM * 8 + NT - 1) / NT, LB = (BN * 8 + NT - 1) / NT;
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
+    static_assert(NW == 4 || (!GLDS && ABL == 0), "the direct-to-LDS and ablation variants are 4-wave only");
     constexpr int NSTAGE = GLDS ? PD : 2;  // LDS stages: the GLDS variant uses PD as its LDS ring depth
     __shared__ __attribute__((aligned(16))) float smem[NSTAGE * (BM + BN) * BK];
 
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g, int kslice, in
     float ln_mu[APRO == 2 ? LA : 1], ln_rs[APRO == 2 ? LA : 1];
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
-        const int gmc = min(m0 + ldrow + i * 32, g.M - 1);
+        const int gmc = min(m0 + ldrow + i * RP, g.M - 1);
         aptr[i] = g.A + (size_t)gmc * g.lda;
         if (APRO == 1) sptr[i] = g.a_scale + (size_t)(gmc / g.a_rows_per_sample) * g.K;
         if (APRO == 2) {
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g, int kslice, in
         }
     }
 #pragma unroll
-    for (int i = 0; i < LB; ++i) bptr[i] = g.W + (size_t)min(n0 + ldrow + i * 32, g.N - 1) * g.ldw;
+    for (int i = 0; i < LB; ++i) bptr[i] = g.W + (size_t)min(n0 + ldrow + i * RP, g.N - 1) * g.ldw;
 
     auto load_tile = [&](Stage& r, int t) {
         const int kc = min(kbeg + t * BK + ldc4 * 4, g.K - 4);
@@ -129,17 +132,17 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g, int kslice, in
         const bool kok = kbeg + t * BK + ldc4 * 4 < kend;
 #pragma unroll
         for (int i = 0; i < LA; ++i) {
-            const int row = ldrow + i * 32;
+            const int row = ldrow + i * RP;
             f32x4 v = r.a[i];
             if (APRO == 1) v = v * r.s[i] + r.t;
             if (APRO == 2) v = (v - ln_mu[i]) * ln_rs[i];
             if (!kok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (LA * 32 == BM || row < BM) *reinterpret_cast<f32x4*>(As + row * BK + ((ldc4 ^ (row & 7)) << 2)) = v;
+            if (LA * RP == BM || row < BM) *reinterpret_cast<f32x4*>(As + row * BK + ((ldc4 ^ (row & 7)) << 2)) = v;
         }
 #pragma unroll
         for (int i = 0; i < LB; ++i) {
-            const int row = ldrow + i * 32;
-            if (LB * 32 == BN || row < BN) *reinterpret_cast<f32x4*>(Bs + row * BK + ((ldc4 ^ (row & 7)) << 2)) = r.b[i];
+            const int row = ldrow + i * RP;
+            if (LB * RP == BN || row < BN) *reinterpret_cast<f32x4*>(Bs + row * BK + ((ldc4 ^ (row & 7)) << 2)) = r.b[i];
         }
     };
     auto store_tile = [&](const Stage& r, int t) { store_tile_slot(r, t, t & 1); };
@@ -316,7 +319,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g, int kslice, in
     if (S > 1) {
         constexpr int FR = TM * TN * 64 * 4;  // floats per wave, fragment order [i][j][lane][4]
         if (!counters) {  // two-launch mode: splitk_reduce_frag_kernel combines
-            float* my = slabs + ((size_t)bid * S + blockIdx.y) * (4 * FR) + (size_t)wave * FR;
+            float* my = slabs + ((size_t)bid * S + blockIdx.y) * (NW * FR) + (size_t)wave * FR;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -327,7 +330,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g, int kslice, in
         // write-through) so no release fence is needed; every storing wave drains vmcnt(0), ONE lane takes a relaxed
         // agent-scope ticket; the last arriver reads all slabs back with sc1 loads (no acquire fence) in FIXED slice order.
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(slabs, 0, (int)slab_bytes, 0x00020000);
-        const unsigned mybase = (unsigned)((((size_t)bid * S + blockIdx.y) * (4 * FR) + (size_t)wave * FR) * sizeof(float));
+        const unsigned mybase = (unsigned)((((size_t)bid * S + blockIdx.y) * (NW * FR) + (size_t)wave * FR) * sizeof(float));
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -343,8 +346,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g, int kslice, in
         TRACE_STAMP(4);
         if (sflag[0] != (unsigned)(S - 1)) return;
         if (tid == 0) __hip_atomic_store(counters + bid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
-        const unsigned tbase = (unsigned)(((size_t)bid * S * (4 * FR) + (size_t)wave * FR) * sizeof(float));
-        const unsigned sstride = (unsigned)(4 * FR * sizeof(float));
+        const unsigned tbase = (unsigned)(((size_t)bid * S * (NW * FR) + (size_t)wave * FR) * sizeof(float));
+        const unsigned sstride = (unsigned)(NW * FR * sizeof(float));
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -409,17 +412,18 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g, int kslice, in
 // Split-K reducer: one workgroup per output tile, same thread -> element mapping as gemm_nt_kernel, so every slab
 // load is a coalesced 1 KiB wave access and the epilogue (incl. the GRN column sums of squares) is shared code.
 template <int WM, int WN, int TM, int TN>
-__global__ __launch_bounds__(256) void splitk_reduce_frag_kernel(GemmArgs g, int S, const float* __restrict__ slabs,
+__global__ __launch_bounds__(64 * WM * WN) void splitk_reduce_frag_kernel(GemmArgs g, int S, const float* __restrict__ slabs,
                                                                  int tiles_m, int tiles_n) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
     constexpr int FR = TM * TN * 64 * 4;
+    constexpr int NW = WM * WN;
     const int bid = blockIdx.x;  // already the remapped tile id used by the producer
     const int tile_m = bid % tiles_m, tile_n = bid / tiles_m;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int r16 = lane & 15, kq = lane >> 4;
-    const float* base = slabs + (size_t)bid * S * (4 * FR) + (size_t)wave * FR;
+    const float* base = slabs + (size_t)bid * S * (NW * FR) + (size_t)wave * FR;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + (wm * TM + i) * 16 + r16;
@@ -429,13 +433,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_frag_kernel(GemmArgs g, int
             f32x4 acc = *reinterpret_cast<const f32x4*>(p);
             int s = 1;
             for (; s + 3 < S; s += 4) {  // 4 loads in flight, added in slice order
-                const f32x4 a0 = *reinterpret_cast<const f32x4*>(p + (size_t)(s + 0) * (4 * FR));
-                const f32x4 a1 = *reinterpret_cast<const f32x4*>(p + (size_t)(s + 1) * (4 * FR));
-                const f32x4 a2 = *reinterpret_cast<const f32x4*>(p + (size_t)(s + 2) * (4 * FR));
-                const f32x4 a3 = *reinterpret_cast<const f32x4*>(p + (size_t)(s + 3) * (4 * FR));
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(p + (size_t)(s + 0) * (NW * FR));
+                const f32x4 a1 = *reinterpret_cast<const f32x4*>(p + (size_t)(s + 1) * (NW * FR));
+                const f32x4 a2 = *reinterpret_cast<const f32x4*>(p + (size_t)(s + 2) * (NW * FR));
+                const f32x4 a3 = *reinterpret_cast<const f32x4*>(p + (size_t)(s + 3) * (NW * FR));
                 acc += a0; acc += a1; acc += a2; acc += a3;
             }
-            for (; s < S; ++s) acc += *reinterpret_cast<const f32x4*>(p + (size_t)s * (4 * FR));
+            for (; s < S; ++s) acc += *reinterpret_cast<const f32x4*>(p + (size_t)s * (NW * FR));
             const int n = n0 + (wn * TN + j) * 16 + kq * 4;
             const bool ok = m < g.M && n < g.N;
             f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -484,6 +488,10 @@ static const TileCfg kCfgs[] = {
     {1, 4, 1, 1},  // 6: 16x64
     {1, 4, 1, 2},  // 7: 16x128
     {1, 4, 2, 2},  // 8: 32x128
+    {2, 4, 4, 2},  // 9: 128x128, 8 waves (64x32 wave tiles): the big tile's operand reuse at twice its occupancy
+    {4, 2, 2, 4},  // 10: 128x128, 8 waves (32x64 wave tiles)
+    {2, 4, 2, 2},  // 11: 64x128, 8 waves
+    {4, 2, 2, 2},  // 12: 128x64, 8 waves
 };
 static const int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
@@ -507,6 +515,7 @@ extern "C" int paella_debug_set_spread(int on) { g_spread = on & 1; g_glds = (on
 template <int WM, int WN, int TM, int TN, int PD>
 static void launch_one(const GemmArgs& g, int kslice, int S, float* slabs, hipStream_t st) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+    constexpr int NT = 64 * WM * WN;
     constexpr int kStaticLds = 2 * (BM + BN) * 32 * 4;
     const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
     dim3 grid(tiles_m * tiles_n, S);
@@ -520,21 +529,21 @@ static void launch_one(const GemmArgs& g, int kslice, int S, float* slabs, hipSt
             if (kStaticLds + pad > 64 * 1024) pad = 64 * 1024 - kStaticLds;   // stay within the default 64 KiB launch limit
         }
     }
-    constexpr bool kCanGlds = (BM % 32 == 0) && (BN % 32 == 0);
+    constexpr bool kCanGlds = NT == 256 && (BM % 32 == 0) && (BN % 32 == 0);
     const bool glds = kCanGlds && g_glds && !g.a_scale && !g.ln_stats && (g.K % 32 == 0) && g.K >= 32;
     unsigned* counters = nullptr;
     const size_t slab_bytes = (size_t)tiles_m * tiles_n * S * BM * BN * sizeof(float);
     if (S > 1 && g_combine && slab_bytes < ((size_t)1 << 31)) (void)gemm_tile_counters(&counters);
     if (g.a_scale)
-        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, PD, 1, false>), grid, dim3(256), pad, st, g, kslice, S, slabs, tiles_m, tiles_n, counters, (unsigned)slab_bytes);
+        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, PD, 1, false>), grid, dim3(NT), pad, st, g, kslice, S, slabs, tiles_m, tiles_n, counters, (unsigned)slab_bytes);
     else if (g.ln_stats)
-        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, PD, 2, false>), grid, dim3(256), pad, st, g, kslice, S, slabs, tiles_m, tiles_n, counters, (unsigned)slab_bytes);
+        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, PD, 2, false>), grid, dim3(NT), pad, st, g, kslice, S, slabs, tiles_m, tiles_n, counters, (unsigned)slab_bytes);
     else if (glds)
-        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, (BM + BN <= 64 ? 4 : (BM + BN <= 128 ? 3 : 2)), 0, kCanGlds>), grid, dim3(256), pad, st, g, kslice, S, slabs, tiles_m, tiles_n, counters, (unsigned)slab_bytes);
+        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, (BM + BN <= 64 ? 4 : (BM + BN <= 128 ? 3 : 2)), 0, kCanGlds>), grid, dim3(NT), pad, st, g, kslice, S, slabs, tiles_m, tiles_n, counters, (unsigned)slab_bytes);
     else
-        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, PD, 0, false>), grid, dim3(256), pad, st, g, kslice, S, slabs, tiles_m, tiles_n, counters, (unsigned)slab_bytes);
+        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, PD, 0, false>), grid, dim3(NT), pad, st, g, kslice, S, slabs, tiles_m, tiles_n, counters, (unsigned)slab_bytes);
     if (S > 1 && !counters)
-        hipLaunchKernelGGL((splitk_reduce_frag_kernel<WM, WN, TM, TN>), dim3(tiles_m * tiles_n), dim3(256), 0, st, g, S, slabs, tiles_m, tiles_n);
+        hipLaunchKernelGGL((splitk_reduce_frag_kernel<WM, WN, TM, TN>), dim3(tiles_m * tiles_n), dim3(NT), 0, st, g, S, slabs, tiles_m, tiles_n);
 }
 
 // ticket counters for the weight-streaming variant's in-launch split-K reduction (gemm_ws.hip)
@@ -568,8 +577,8 @@ static void choose_config(int M, int N, int K, size_t ws_bytes, int* cfg_out, in
     const int ktiles = (K + 31) / 32;
     int cfg, S = 1;
     const double macs = (double)M * N * K;
-    if (tiles_of(0) >= 2048 || (tiles_of(0) >= 1024 && K <= 512)) {  // >= 8 workgroups of 128x128 per CU: the big tile wins at any K (120-128 TF)
-        cfg = 0;
+    if (tiles_of(0) >= 1024) {  // >= 4 workgroups of 128x128 per CU: the big tile with 8 waves (32x64 wave tiles) wins at any K (121-128 TF)
+        cfg = 10;
     } else if (tiles_of(2) >= 1024 || macs >= 3e9) {  // big problems: 64x64 tiles, split only to reach ~1024 workgroups
         cfg = 2;
         const long t = tiles_of(2);
@@ -736,6 +745,10 @@ static int launch_gemm_cfg_impl(const GemmArgs& g, int cfg, int splitk, void* ws
             case 6: launch_one<1, 4, 1, 1, 2>(g, kslice, S, slabs, st); break;
             case 7: launch_one<1, 4, 1, 2, 2>(g, kslice, S, slabs, st); break;
             case 8: launch_one<1, 4, 2, 2, 2>(g, kslice, S, slabs, st); break;
+            case 9: launch_one<2, 4, 4, 2, 2>(g, kslice, S, slabs, st); break;
+            case 10: launch_one<4, 2, 2, 4, 2>(g, kslice, S, slabs, st); break;
+            case 11: launch_one<2, 4, 2, 2, 2>(g, kslice, S, slabs, st); break;
+            case 12: launch_one<4, 2, 2, 2, 2>(g, kslice, S, slabs, st); break;
         }
     } else {  // 1-deep prefetch variants kept for A/B measurements (tools/gemm_tune.py, cfg + 32)
         switch (cfg) {

@@ -46,6 +46,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=None)
     ap.add_argument("--iters", type=int, default=30)
+    ap.add_argument("--big-only", action="store_true", help="only the large-tile candidates without split-K")
     ap.add_argument("--only", default=None, help="substring filter on the shape name")
     a = ap.parse_args()
     lib = _lib.load()
@@ -64,8 +65,10 @@ def main():
         C = torch.empty(M, N, device="cuda")
         row = {}
         variants = [(-1, 1)] + [(c, s) for c in range(9) for s in (1, 2, 4, 8, 16)] + [(c, s) for c in (34, 36, 37) for s in (1, 2, 4, 8, 16)]
+        if a.big_only:
+            variants = [(-1, 1)] + [(c, 1) for c in (0, 1, 2, 9, 10, 11, 12, 34)]
         if M >= 4096:  # MFMA-bound: no split-K, few candidates, few iterations
-            variants = [(-1, 1)] + [(c, 1) for c in (0, 1, 2, 3, 8, 34)]
+            variants = [(-1, 1)] + [(c, 1) for c in (0, 1, 2, 9, 10, 11, 12, 34)]
         for cfg, sk in variants:
             if sk > 1 and (K // sk < 128 or sk * max(M, 128) * N * 4 > ws.numel()):
                 continue
@@ -93,7 +96,7 @@ def main():
                          "heuristic_us": heur, "heuristic_tflops": round(flops / heur / 1e6, 1) if heur else None,
                          "hbm_floor_us": round((M * K + N * K + M * N) * 4 / 6.3e6, 2), "mfma_floor_us": round(flops / 157.3e6, 2)}
         r = results[name]
-        print("%-34s all %s" % (name, " ".join("%s=%.0f" % kv for kv in row.items())) if M >= 4096 else "", end="\n" if M >= 4096 else "")
+        print("%-34s all %s" % (name, " ".join("%s=%.0f" % kv for kv in row.items())) if (M >= 4096 or a.big_only) else "", end="\n" if (M >= 4096 or a.big_only) else "")
         print("%-28s best %-6s %8.1f us %6.1f TF | heuristic %8.1f us %6.1f TF | best PD=1 %-6s %6.1f us | floors hbm %.1f mfma %.1f us" %
               (name, r["best"], r["best_us"], r["best_tflops"], heur, r["heuristic_tflops"], pd1[1], pd1[0], r["hbm_floor_us"], r["mfma_floor_us"]), flush=True)
     if a.out:
