@@ -131,7 +131,7 @@ def main():
 
     import paella_amd
     from paella_amd import _lib, synth
-    from paella_amd.dist import broadcast_conditioning, shard_bounds, shard_inputs
+    from paella_amd.dist import broadcast_conditioning, conditioning_layout, shard_bounds, shard_inputs
     lib = _lib.load()  # fails loudly if the HIP library is missing
     paella_amd.set_gemm_precision(a.gemm)
 
@@ -150,6 +150,9 @@ def main():
         cond_all = synth.synth_conditioning(total, 0, mcfg["byt5_embd"], mcfg["clip_embd"], seed=2, device=device)
         uncond_all = synth.synth_conditioning(total, 0, mcfg["byt5_embd"], mcfg["clip_embd"], seed=3, device=device)
     lo, hi = shard_bounds(total, rank, world)
+    # fixed request shapes: every rank derives the broadcast layout locally, so the per-step exchange is ONE async RCCL broadcast
+    tmpl = synth.synth_conditioning(total, 0, mcfg["byt5_embd"], mcfg["clip_embd"], seed=2, device=device)
+    layout = conditioning_layout([tmpl, tmpl]) if distributed else None
     counter = [0]
     use_graph = not a.no_graph and a.noise == "philox"
     sampler = None
@@ -162,7 +165,7 @@ def main():
 
     def step():
         if distributed:
-            c, u = broadcast_conditioning([cond_all, uncond_all] if rank == 0 else None, src=0, device=device)
+            c, u = broadcast_conditioning([cond_all, uncond_all] if rank == 0 else None, src=0, device=device, layout=layout)
             c, u = shard_inputs(c, lo, hi), shard_inputs(u, lo, hi)
         else:
             c, u = cond_all, uncond_all

@@ -59,9 +59,23 @@ def _unflatten(flat, desc, device):
     return out
 
 
-def broadcast_conditioning(input_sets, src=0, device=None, group=None):
+def conditioning_layout(input_sets):
+    """(structure descriptors, total element count) of a list of conditioning dicts.  Every rank that knows the shapes
+    (fixed-shape serving: same batch, sequence lengths and widths per request) can compute it locally from same-shaped
+    tensors and pass it as `layout=` to broadcast_conditioning, which then needs no shape exchange."""
+    descs, numel = [], 0
+    for s in input_sets:
+        ts, d = _flatten_inputs(s)
+        descs.append(d)
+        numel += sum(t.numel() for t in ts)
+    return descs, numel
+
+
+def broadcast_conditioning(input_sets, src=0, device=None, group=None, layout=None):
     """Broadcast a list of conditioning dicts (e.g. [model_inputs, unconditional_inputs]) from `src` with ONE
-    tensor collective (plus one small object broadcast for the shapes).  Non-source ranks pass None."""
+    tensor collective.  Non-source ranks pass None.  Without `layout` the shapes travel first in one small object
+    broadcast (which synchronises host and device); with `layout` = conditioning_layout(...) known on every rank the
+    call is a single asynchronous RCCL broadcast on the current stream."""
     rank = dist.get_rank(group)
     meta = [None]
     flat = None
@@ -74,8 +88,13 @@ def broadcast_conditioning(input_sets, src=0, device=None, group=None):
         device = all_tensors[0].device if device is None else torch.device(device)
         flat = torch.cat([t.reshape(-1).float() for t in all_tensors]).to(device) if all_tensors else torch.zeros(0, device=device)
         meta = [(descs, flat.numel())]
-    dist.broadcast_object_list(meta, src=src, group=group)
-    descs, numel = meta[0]
+        if layout is not None and (layout[1] != flat.numel() or layout[0] != descs):
+            raise ValueError("conditioning does not match the agreed layout")
+    if layout is None:
+        dist.broadcast_object_list(meta, src=src, group=group)
+        descs, numel = meta[0]
+    else:
+        descs, numel = layout
     if rank != src:
         if device is None:
             raise ValueError("non-source ranks must pass device")

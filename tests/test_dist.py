@@ -6,7 +6,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from paella_amd.dist import broadcast_conditioning, shard_bounds, shard_inputs
+from paella_amd.dist import broadcast_conditioning, conditioning_layout, shard_bounds, shard_inputs
 
 
 def _free_port():
@@ -31,6 +31,11 @@ def _worker(rank, world, port, q):
         ok = torch.equal(got_c["byt5"], cond["byt5"]) and torch.equal(got_c["clip"], cond["clip"])
         ok = ok and all(torch.equal(a, b) for a, b in zip(got_c["clip_image"], cond["clip_image"]))
         ok = ok and torch.equal(got_u["byt5"], uncond["byt5"]) and got_u["clip_image"] is None
+        # fixed-shape serving: every rank derives the layout from same-shaped tensors -> one collective, no shape exchange
+        layout = conditioning_layout([cond, uncond])  # (both ranks built the same tensors from the same seed here)
+        lay_c, lay_u = broadcast_conditioning([cond, uncond] if rank == 0 else None, src=0, device="cpu", layout=layout)
+        ok = ok and torch.equal(lay_c["byt5"], cond["byt5"]) and torch.equal(lay_u["clip"], uncond["clip"]) and lay_u["clip_image"] is None
+        ok = ok and all(torch.equal(a, b) for a, b in zip(lay_c["clip_image"], cond["clip_image"]))
         lo, hi = shard_bounds(B, rank, world)
         mine = shard_inputs(got_c, lo, hi)
         # gather the shards back: sharded == unsharded
