@@ -68,6 +68,58 @@ float run_frag(const std::vector<float*>& Ws, float* out, int N, int K, int S, h
     return best * 1e3f / Ws.size();
 }
 
+// Operand-fetch phase of a "no LDS, no barrier" skinny GEMM: 32x32 output tile per 4-wave workgroup, the four waves split the
+// K slice, every wave pulls its A (2 x 16 rows) and W (2 x 16 rows) MFMA fragments straight from global memory / L2.
+// Measures whether the vector-memory path can deliver the 8 KB per 32x32x32 tile step faster than the LDS-staged kernel.
+template <int NG>
+__global__ __launch_bounds__(256) void probe_gemm_frag(const float* __restrict__ A, const float* __restrict__ W, float* __restrict__ out,
+                                                       int M, int N, int K, int kslice) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int tiles_m = M / 32;
+    const int tm = blockIdx.x % tiles_m, tn = blockIdx.x / tiles_m;
+    const int kq4 = kq * 4;
+    const float* a0 = A + (size_t)(tm * 32 + r16) * K + (size_t)blockIdx.y * kslice + kq4;
+    const float* a1 = a0 + (size_t)16 * K;
+    const float* w0 = W + (size_t)(tn * 32 + r16) * K + (size_t)blockIdx.y * kslice + kq4;
+    const float* w1 = w0 + (size_t)16 * K;
+    float acc = 0.f;
+    const int groups = kslice / 16;  // 16-k groups of the slice; wave w takes groups w, w+4, ...
+    for (int g0 = wave; g0 < groups; g0 += 4 * NG) {
+        float4 ra[NG], rb[NG], rc[NG], rd[NG];
+#pragma unroll
+        for (int d = 0; d < NG; ++d) {
+            const int k = min(g0 + 4 * d, groups - 1) * 16;
+            ra[d] = *reinterpret_cast<const float4*>(a0 + k);
+            rb[d] = *reinterpret_cast<const float4*>(a1 + k);
+            rc[d] = *reinterpret_cast<const float4*>(w0 + k);
+            rd[d] = *reinterpret_cast<const float4*>(w1 + k);
+        }
+#pragma unroll
+        for (int d = 0; d < NG; ++d) acc += ra[d].x + rb[d].y + rc[d].z + rd[d].w;
+    }
+    if (acc == 12345.678f) out[t] = acc;
+}
+
+template <int NG>
+float run_gemm_frag(const float* A, const std::vector<float*>& Ws, float* out, int M, int N, int K, int S, hipStream_t st) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    dim3 grid((M / 32) * (N / 32), S);
+    float best = 1e9f;
+    for (int rep = 0; rep < 5; ++rep) {
+        hipEventRecord(e0, st);
+        for (float* W : Ws) probe_gemm_frag<NG><<<grid, 256, 0, st>>>(A, W, out, M, N, K, K / S);
+        hipEventRecord(e1, st);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+    }
+    return best * 1e3f / Ws.size();
+}
+
 template <int D, bool TILED>
 float run(const std::vector<float*>& Ws, float* out, int N, int K, int S, hipStream_t st) {
     hipEvent_t e0, e1;
@@ -112,6 +164,17 @@ int main(int argc, char** argv) {
         if ((K / S) % 320) continue;
         printf("fragment pattern (16 rows x 64 B per wave load), S=%d (%4d WGs): NG=4,10,20 in flight: %6.1f %6.1f %6.1f us\n", S, N / 64 * S,
                run_frag<4>(Ws, out, N, K, S, st), run_frag<10>(Ws, out, N, K, S, st), run_frag<20>(Ws, out, N, K, S, st));
+    }
+    {   // operand-fetch phase of the barrier-free skinny GEMM, M = 128 rows of activations (L2-resident)
+        const int M = 128;
+        float* A;
+        hipMalloc(&A, (size_t)M * K * 4);
+        hipMemset(A, 0, (size_t)M * K * 4);
+        for (int S : {1, 2, 4})
+            if ((K / S) % 64 == 0)
+                printf("barrier-free GEMM operand fetch, M=128: S=%d (%4d WGs): 2,5,10 groups in flight per wave: %6.1f %6.1f %6.1f us\n", S,
+                       (M / 32) * (N / 32) * S, run_gemm_frag<2>(A, Ws, out, M, N, K, S, st), run_gemm_frag<5>(A, Ws, out, M, N, K, S, st),
+                       run_gemm_frag<10>(A, Ws, out, M, N, K, S, st));
     }
     return 0;
 }
