@@ -154,7 +154,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs g, int k
     auto compute = [&](int t) {
         const float* As = smem + (GLDS ? (t % NSTAGE) : (t & 1)) * (BM + BN) * BK;
         const float* Bs = As + BM * BK;
-        constexpr bool FRAG_FIRST = (TM * TN <= 2);  // small wave tiles: all fragment reads up front; big ones: per 16-k group (VGPRs)
+        // small wave tiles and the 8-wave 128x128 configs (2 workgroups of 8 waves per CU: little else hides the LDS latency):
+        // all fragment reads of the tile up front; the other big ones: per 16-k group (VGPRs)
+        constexpr bool FRAG_FIRST = (TM * TN <= 2) || (NW == 8 && TM + TN <= 6 && PD == 1);
         if constexpr (FRAG_FIRST) {
             f32x4 af[2][TM], bf[2][TN];
             if (ABL == 3) {  // ablation: MFMA only, operands from registers
@@ -492,6 +494,8 @@ static const TileCfg kCfgs[] = {
     {4, 2, 2, 4},  // 10: 128x128, 8 waves (32x64 wave tiles)
     {2, 4, 2, 2},  // 11: 64x128, 8 waves
     {4, 2, 2, 2},  // 12: 128x64, 8 waves
+    {2, 4, 4, 2},  // 13: = 9, fragment-first
+    {4, 2, 2, 4},  // 14: = 10, fragment-first
 };
 static const int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
@@ -578,7 +582,7 @@ static void choose_config(int M, int N, int K, size_t ws_bytes, int* cfg_out, in
     int cfg, S = 1;
     const double macs = (double)M * N * K;
     if (tiles_of(0) >= 1024) {  // >= 4 workgroups of 128x128 per CU: the big tile with 8 waves (32x64 wave tiles) wins at any K (121-128 TF)
-        cfg = 10;
+        cfg = 14;
     } else if (tiles_of(2) >= 1024 || macs >= 3e9) {  // big problems: 64x64 tiles, split only to reach ~1024 workgroups
         cfg = 2;
         const long t = tiles_of(2);
@@ -747,6 +751,8 @@ static int launch_gemm_cfg_impl(const GemmArgs& g, int cfg, int splitk, void* ws
             case 8: launch_one<1, 4, 2, 2, 2>(g, kslice, S, slabs, st); break;
             case 9: launch_one<2, 4, 4, 2, 2>(g, kslice, S, slabs, st); break;
             case 10: launch_one<4, 2, 2, 4, 2>(g, kslice, S, slabs, st); break;
+            case 13: launch_one<2, 4, 4, 2, 1>(g, kslice, S, slabs, st); break;  // as 9 / 10 with all fragment reads up front (1-deep global prefetch)
+            case 14: launch_one<4, 2, 2, 4, 1>(g, kslice, S, slabs, st); break;
             case 11: launch_one<2, 4, 2, 2, 2>(g, kslice, S, slabs, st); break;
             case 12: launch_one<4, 2, 2, 2, 2>(g, kslice, S, slabs, st); break;
         }

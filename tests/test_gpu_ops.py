@@ -49,7 +49,7 @@ def test_gemm_heuristic(lib, M, N, K):
     np.testing.assert_allclose(C.cpu().numpy(), ref.numpy(), atol=2e-5 * max(1, K ** 0.5 / 8), rtol=1e-5)
 
 
-@pytest.mark.parametrize("cfg", list(range(13)) + list(range(16, 25)) + [34, 36, 37])
+@pytest.mark.parametrize("cfg", list(range(15)) + list(range(16, 25)) + [34, 36, 37])
 @pytest.mark.parametrize("splitk", [1, 3])
 def test_gemm_every_tile_config(lib, cfg, splitk):
     M, N, K = 200, 328, 416  # ragged in every dimension

@@ -47,9 +47,11 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--big-only", action="store_true", help="only the large-tile candidates without split-K")
+    ap.add_argument("--debug-switches", type=int, default=0, help="paella_debug_set_spread bits (2 = direct global->LDS staging)")
     ap.add_argument("--only", default=None, help="substring filter on the shape name")
     a = ap.parse_args()
     lib = _lib.load()
+    lib.paella_debug_set_spread(a.debug_switches)
     st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     ws = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
     results = {}
@@ -66,9 +68,9 @@ def main():
         row = {}
         variants = [(-1, 1)] + [(c, s) for c in range(9) for s in (1, 2, 4, 8, 16)] + [(c, s) for c in (34, 36, 37) for s in (1, 2, 4, 8, 16)]
         if a.big_only:
-            variants = [(-1, 1)] + [(c, 1) for c in (0, 1, 2, 9, 10, 11, 12, 34)]
+            variants = [(-1, 1)] + [(c, 1) for c in (0, 1, 2, 9, 10, 11, 12, 13, 14, 34)]
         if M >= 4096:  # MFMA-bound: no split-K, few candidates, few iterations
-            variants = [(-1, 1)] + [(c, 1) for c in (0, 1, 2, 9, 10, 11, 12, 34)]
+            variants = [(-1, 1)] + [(c, 1) for c in (0, 1, 2, 9, 10, 11, 12, 13, 14, 34)]
         for cfg, sk in variants:
             if sk > 1 and (K // sk < 128 or sk * max(M, 128) * N * 4 > ws.numel()):
                 continue

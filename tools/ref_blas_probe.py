@@ -3,9 +3,10 @@ measured the same way as tools/gemm_tune.py (rotating cold weights, back-to-back
 import torch
 torch.backends.cuda.matmul.allow_tf32 = False
 shapes = [(128, 5120, 1280), (128, 1280, 5120), (32, 5120, 1280), (32, 1280, 5120), (512, 2560, 640), (512, 640, 2560), (128, 3840, 1280),
-          (128, 1280, 1280), (1024, 5120, 1280), (4096, 2560, 640), (2048, 8192, 256)]
+          (128, 1280, 1280), (1024, 5120, 1280), (4096, 2560, 640), (2048, 8192, 256),
+          (4096, 5120, 1280), (4096, 1280, 5120), (16384, 2560, 640), (32768, 5120, 1280), (32768, 1280, 5120), (131072, 2560, 640), (131072, 640, 2560)]
 for M, N, K in shapes:
-    ncopy = max(2, min(64, int(600e6 // (N * K * 4)) + 1))
+    ncopy = max(2, min(64, int(600e6 // (N * K * 4)) + 1)) if M < 4096 else 3
     A = torch.randn(M, K, device="cuda")
     Ws = [torch.randn(N, K, device="cuda") for _ in range(ncopy)]
     C = torch.empty(M, N, device="cuda")
