@@ -504,7 +504,7 @@ static const int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 // kernel, every tile config ~26 us where the matrix-core floor is 11 us).  Reserving unused dynamic LDS caps the
 // workgroups per CU at ceil(grid / 256) so a sub-capacity grid spreads over the whole chip.
 static int g_spread = 0;
-int gemm_tile_counters(unsigned** out);
+int gemm_tile_counters(unsigned** out, hipStream_t st);
 static int g_combine = 1;  // in-launch split-K combine with write-through (sc1) slabs
 static int g_glds = 0;  // measured neutral-to-negative on MI355X for these shapes (tools/gemm_warm_cold.py); kept for A/B
 // debug switches for A/B measurements: bit 0 = workgroup spreading (LDS reservation), bit 1 = direct global->LDS staging
@@ -537,7 +537,7 @@ static void launch_one(const GemmArgs& g, int kslice, int S, float* slabs, hipSt
     const bool glds = kCanGlds && g_glds && !g.a_scale && !g.ln_stats && (g.K % 32 == 0) && g.K >= 32;
     unsigned* counters = nullptr;
     const size_t slab_bytes = (size_t)tiles_m * tiles_n * S * BM * BN * sizeof(float);
-    if (S > 1 && g_combine && slab_bytes < ((size_t)1 << 31)) (void)gemm_tile_counters(&counters);
+    if (S > 1 && g_combine && slab_bytes < ((size_t)1 << 31)) (void)gemm_tile_counters(&counters, st);
     if (g.a_scale)
         hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, PD, 1, false>), grid, dim3(NT), pad, st, g, kslice, S, slabs, tiles_m, tiles_n, counters, (unsigned)slab_bytes);
     else if (g.ln_stats)
@@ -550,15 +550,27 @@ static void launch_one(const GemmArgs& g, int kslice, int S, float* slabs, hipSt
         hipLaunchKernelGGL((splitk_reduce_frag_kernel<WM, WN, TM, TN>), dim3(tiles_m * tiles_n), dim3(NT), 0, st, g, S, slabs, tiles_m, tiles_n);
 }
 
-// ticket counters for the weight-streaming variant's in-launch split-K reduction (gemm_ws.hip)
-static unsigned* g_counters = nullptr;
+// Split-K ticket counters (one word per output tile, zero between launches).  Launches on DIFFERENT streams may run
+// concurrently, so every stream gets its own block out of a small pool allocated once (no allocation later: the first
+// launch on a new stream may already be under stream capture).  More than kPoolBlocks concurrent streams share blocks.
+static unsigned* g_counter_pool = nullptr;
 static const int kMaxTiles = 1 << 16;
-int gemm_tile_counters(unsigned** out) {
-    if (!g_counters) {
-        HIP_CHECK_RET(hipMalloc((void**)&g_counters, kMaxTiles * sizeof(unsigned)));
-        HIP_CHECK_RET(hipMemset(g_counters, 0, kMaxTiles * sizeof(unsigned)));
+static const int kPoolBlocks = 8;
+static std::vector<hipStream_t> g_pool_streams;
+int gemm_tile_counters(unsigned** out, hipStream_t st) {
+    if (!g_counter_pool) {
+        HIP_CHECK_RET(hipMalloc((void**)&g_counter_pool, (size_t)kPoolBlocks * kMaxTiles * sizeof(unsigned)));
+        HIP_CHECK_RET(hipMemset(g_counter_pool, 0, (size_t)kPoolBlocks * kMaxTiles * sizeof(unsigned)));
+        HIP_CHECK_RET(hipDeviceSynchronize());
     }
-    *out = g_counters;
+    size_t idx = 0;
+    for (; idx < g_pool_streams.size(); ++idx)
+        if (g_pool_streams[idx] == st) break;
+    if (idx == g_pool_streams.size()) {
+        if (g_pool_streams.size() < (size_t)kPoolBlocks) g_pool_streams.push_back(st);
+        else idx = ((size_t)(uintptr_t)st >> 4) % kPoolBlocks;
+    }
+    *out = g_counter_pool + idx * kMaxTiles;
     return PAELLA_OK;
 }
 int gemm_max_tiles() { return kMaxTiles; }
@@ -702,7 +714,7 @@ static int launch_gemm_cfg_impl(const GemmArgs& g, int cfg, int splitk, void* ws
     } while (0)
         if (abl == 4) {  // timeline probe: the real kernel (in-launch combine) with time stamps
             unsigned* ctr = nullptr;
-            if (Sx > 1) RET_IF_G(gemm_tile_counters(&ctr));
+            if (Sx > 1) RET_IF_G(gemm_tile_counters(&ctr, st));
 #define TL_LAUNCH(WMv, WNv, TMv, TNv)                                                                                          \
     do {                                                                                                                       \
         constexpr int BM = WMv * TMv * 16, BN = WNv * TNv * 16;                                                                \

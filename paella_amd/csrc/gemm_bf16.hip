@@ -304,7 +304,7 @@ static const unsigned short* shadow_lookup(const float* W) {
 // ---------------------------------------------------------------------------
 // launcher
 // ---------------------------------------------------------------------------
-int gemm_tile_counters(unsigned** out);  // gemm.hip
+int gemm_tile_counters(unsigned** out, hipStream_t st);  // gemm.hip
 int gemm_max_tiles();
 
 template <int WM, int WN, int TM, int TN>
@@ -314,7 +314,7 @@ static void launch_b(const GemmArgs& g, const unsigned short* Wb, int kslice, in
     dim3 grid(tiles_m * tiles_n, S);
     unsigned* counters = nullptr;
     const size_t slab_bytes = (size_t)tiles_m * tiles_n * S * BM * BN * sizeof(float);
-    if (S > 1) (void)gemm_tile_counters(&counters);
+    if (S > 1) (void)gemm_tile_counters(&counters, st);
     if (g.a_scale)
         hipLaunchKernelGGL((gemm_bf16_kernel<WM, WN, TM, TN, 1>), grid, dim3(256), 0, st, g, Wb, kslice, S, slabs, tiles_m, tiles_n, counters, (unsigned)slab_bytes);
     else if (g.ln_stats)

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(GemmArgs g, int kslice, in
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
-int gemm_tile_counters(unsigned** out);  // gemm.hip
+int gemm_tile_counters(unsigned** out, hipStream_t st);  // gemm.hip
 int gemm_max_tiles();
 
 template <int TM, int NKG>
@@ -209,7 +209,7 @@ static void launch_ws(const GemmArgs& g, int kslice, int S, float* slabs, unsign
 int launch_gemm_ws(const GemmArgs& g, int tm_code, int nk_code, int splitk, void* ws, size_t ws_bytes, hipStream_t st) {
     if (tm_code < 0 || tm_code > 2 || nk_code < 0 || nk_code > 2) { paella_set_error("gemm_ws: bad tile code"); return PAELLA_ERR_ARG; }
     unsigned* ctr = nullptr;
-    { const int rc = gemm_tile_counters(&ctr); if (rc != PAELLA_OK) return rc; }
+    { const int rc = gemm_tile_counters(&ctr, st); if (rc != PAELLA_OK) return rc; }
     const int BM = 16 << tm_code, BN = 64;
     const int cap = nk_code == 0 ? 128 : (nk_code == 1 ? 192 : 320);
     const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;

@@ -365,11 +365,11 @@ extern "C" int paella_unet_set_timestep_freqs(paella_unet* m, const float* host_
     return PAELLA_OK;
 }
 
-int gemm_tile_counters(unsigned** out);  // gemm.hip
+int gemm_tile_counters(unsigned** out, hipStream_t st);  // gemm.hip
 
 extern "C" int paella_unet_finalize(paella_unet* m, void* stream) {
     if (!m) { paella_set_error("null argument"); return PAELLA_ERR_ARG; }
-    { unsigned* ctr = nullptr; RET_IF(gemm_tile_counters(&ctr)); }  // allocate the split-K tickets now: a first forward may run under stream capture
+    { unsigned* ctr = nullptr; RET_IF(gemm_tile_counters(&ctr, (hipStream_t)stream)); }  // allocate the split-K tickets now: a first forward may run under stream capture
     for (auto& kv : m->t)  // bf16 shadow copies for the opt-in fast mode are (re)made from the tensors as loaded now
         if (kv.second.p && kv.second.n >= 4096) RET_IF(gemm_register_weight(kv.second.p, kv.second.n, (hipStream_t)stream));
     for (auto& kv : m->specs) {

@@ -156,11 +156,11 @@ extern "C" int paella_vqgan_load_tensor(paella_vqgan* v, const char* key, const 
     return repack_into(sp.kind, dev_src, sp.shape, v->t[key], (hipStream_t)stream);
 }
 
-int gemm_tile_counters(unsigned** out);  // gemm.hip
+int gemm_tile_counters(unsigned** out, hipStream_t st);  // gemm.hip
 
 extern "C" int paella_vqgan_finalize(paella_vqgan* v, void* stream) {
     if (!v) { paella_set_error("null argument"); return PAELLA_ERR_ARG; }
-    { unsigned* ctr = nullptr; RET_IF(gemm_tile_counters(&ctr)); }  // split-K tickets must exist before any captured launch
+    { unsigned* ctr = nullptr; RET_IF(gemm_tile_counters(&ctr, (hipStream_t)stream)); }  // split-K tickets must exist before any captured launch
     hipStream_t st = (hipStream_t)stream;
     for (auto& kv : v->specs) {
         auto it = v->t.find(kv.first);

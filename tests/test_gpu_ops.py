@@ -259,3 +259,30 @@ def test_sample_tail_philox_distribution(lib):
     outm, pre = _tail(lib, lc, None, 1.0, 0.0, 0.8, 0, None, init, None, 0.3, seed=9)
     frac = ((outm == 7) & (pre != 7)).double().sum() / (pre != 7).double().sum()
     assert abs(float(frac) - 0.3) < 0.02
+
+
+def test_gemm_split_k_on_two_streams_concurrently(lib):
+    """Split-K tickets are per stream: two streams running split-K GEMMs at the same time do not disturb each other."""
+    g = torch.Generator().manual_seed(5)
+    shapes = [(128, 1280, 5120), (96, 640, 2560)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    data = []
+    for (M, N, K) in shapes:
+        A, W = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / 50
+        data.append((A.cuda(), W.cuda(), (A.double() @ W.double().t()).float(), torch.empty(64 << 20, dtype=torch.uint8, device="cuda")))
+    torch.cuda.synchronize()
+    outs = [[], []]
+    for it in range(40):
+        for i, s in enumerate(streams):
+            Ad, Wd, _, ws = data[i]
+            M, K = Ad.shape
+            N = Wd.shape[0]
+            with torch.cuda.stream(s):
+                C = torch.full((M, N), float("nan"), device="cuda")
+                _check(lib, lib.paella_op_gemm(_p(Ad), _p(Wd), None, None, _p(C), M, N, K, 0, 5, 8, _p(ws), ws.numel(),
+                                               ctypes.c_void_p(s.cuda_stream)))
+                outs[i].append(C)
+    torch.cuda.synchronize()
+    for i in range(2):
+        np.testing.assert_allclose(outs[i][0].cpu().numpy(), data[i][2].numpy(), atol=2e-4, rtol=2e-5)
+        assert all(torch.equal(outs[i][0], o) for o in outs[i][1:])
