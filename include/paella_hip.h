@@ -14,6 +14,9 @@
  *     thread-local description of the last failure.  Nothing throws across this boundary;
  *   - the library owns only its repacked weight copies; activations, conditioning caches and workspaces are
  *     caller-owned device buffers whose sizes come from the *_bytes() queries;
+ *   - every workspace (`ws`) begins with a small header of split-K arrival tickets: call paella_workspace_init() once
+ *     on a freshly allocated workspace (a stream-ordered memset); the kernels leave the header zero afterwards.  One
+ *     workspace must not be shared by calls that can run concurrently (one per stream / per captured graph);
  *   - handles are not thread-safe: one host thread per model per GPU (the reference's one-process-per-GPU
  *     layout, src_distributed/train.py:186-189).
  *   - activations inside the library are NHWC; logits are returned position-major [B, H, W, num_labels]
@@ -29,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PAELLA_ABI_VERSION 1
+#define PAELLA_ABI_VERSION 2
 
 #define PAELLA_OK 0
 #define PAELLA_ERR_ARG -1       /* invalid argument / unsupported shape */
@@ -42,6 +45,11 @@ extern "C" {
 
 int paella_abi_version(void);
 const char* paella_last_error(void);
+
+/* Zeroes the header (paella_workspace_header_bytes() bytes) of a freshly allocated workspace; required once before the
+ * workspace is first passed to any entry point below.  Enqueued on `stream`, no host synchronisation. */
+int paella_workspace_init(void* ws, size_t ws_bytes, void* stream);
+size_t paella_workspace_header_bytes(void);
 
 /* ------------------------------------------------------------------------------------------------
  * Denoising UNet ("Paella", reference src/modules.py:109-283; alias DenoiseUNet)
@@ -183,7 +191,9 @@ int paella_vqgan_quantize_rows(paella_vqgan* v, const float* x, int64_t rows, in
 /* ------------------------------------------------------------------------------------------------
  * Single-op entry points (used by the parity tests and the kernel micro-benchmarks)
  * ---------------------------------------------------------------------------------------------- */
-/* C[M,N] = act(A[M,K] . W[N,K]^T + bias) (+ residual); tile_cfg < 0 = heuristic; act: 0 none, 1 GELU(erf) */
+/* C[M,N] = act(A[M,K] . W[N,K]^T + bias) (+ residual); act: 0 none, 1 GELU(erf).  tile_cfg < 0 = heuristic; otherwise a
+ * tile id with splitk > 0 -> tiles * splitk workgroups (classic split-K), splitk < 0 -> exactly -splitk workgroups walking
+ * balanced contiguous (tile, K-step) ranges.  ws = an initialised workspace (split-K tickets + slabs) or NULL. */
 int paella_op_gemm(const float* A, const float* W, const float* bias, const float* residual, float* C, int M, int N,
                    int K, int act, int tile_cfg, int splitk, void* ws, size_t ws_bytes, void* stream);
 int paella_op_layernorm(const float* x, float* y, int64_t rows, int C, float eps, void* stream);
@@ -204,16 +214,6 @@ int paella_op_attention(const float* q, const float* k_self, const float* v_self
  * ---------------------------------------------------------------------------------------------- */
 int paella_prof_enable(int on);
 int paella_prof_collect(double* total_ms, double* total_flops, double* total_bytes, int64_t* launches);
-/* launches n_launches dependent, nearly empty kernels (blocks x 256 threads touching n_elems floats): boundary floor */
-int paella_debug_launch_chain(float* buf, int n_elems, int blocks, int n_launches, void* stream);
-/* A/B switch for the GEMM workgroup-spreading LDS reservation (default on) */
-int paella_debug_set_spread(int on);
-/* Test hook: (un)register an arbitrary fp32 [N,K] matrix for the bf16 fast mode so paella_op_gemm(tile_cfg 96..98) can use it. */
-int paella_debug_register_weight(const float* w, size_t numel, int on);
-/* Timeline probe (tools/gemm_timeline.py): device buffer of 8 x uint64 per workgroup that the probe build of the GEMM
- * (tile config 128 + tile) fills with 100 MHz wall-clock stamps; NULL switches it off. */
-int paella_debug_set_trace(void* dev_buf);
-
 #ifdef __cplusplus
 }
 #endif

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libpaella_hip.so")
 
 MAX_LEVELS = 8
 MAX_BLOCK_TYPES = 8
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class UnetConfig(Structure):
@@ -38,6 +38,8 @@ class VqganConfig(Structure):
 SIGNATURES = {
     "paella_abi_version": (c_int, []),
     "paella_last_error": (c_char_p, []),
+    "paella_workspace_init": (c_int, [c_void_p, c_size_t, c_void_p]),
+    "paella_workspace_header_bytes": (c_size_t, []),
     "paella_unet_create": (c_int, [POINTER(UnetConfig), POINTER(c_void_p)]),
     "paella_unet_destroy": (None, [c_void_p]),
     "paella_unet_load_tensor": (c_int, [c_void_p, c_char_p, c_void_p, POINTER(c_int64), c_int, c_void_p]),
@@ -72,12 +74,8 @@ SIGNATURES = {
     "paella_vqgan_quantize_rows": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "paella_prof_enable": (c_int, [c_int]),
     "paella_prof_collect": (c_int, [POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int64)]),
-    "paella_debug_set_spread": (c_int, [c_int]),
-    "paella_debug_register_weight": (c_int, [c_void_p, c_size_t, c_int]),
     "paella_set_gemm_precision": (c_int, [c_int]),
     "paella_get_gemm_precision": (c_int, []),
-    "paella_debug_set_trace": (c_int, [c_void_p]),
-    "paella_debug_launch_chain": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     "paella_op_gemm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                c_void_p, c_size_t, c_void_p]),
     "paella_op_layernorm": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]),
@@ -86,6 +84,12 @@ SIGNATURES = {
     "paella_op_grn_scale": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "paella_op_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                     c_int, c_int, c_void_p, c_int, c_void_p]),
+}
+
+# exported for tests / tools only; declared in paella_amd/csrc/test_hooks.h, not in the public header
+TEST_HOOKS = {
+    "paella_test_register_weight": (c_int, [c_void_p, c_size_t, c_int]),
+    "paella_test_launch_chain": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
 }
 
 _lib = None
@@ -108,7 +112,7 @@ def load():
         lib = ctypes.CDLL(LIB_PATH)
     except OSError as e:
         raise PaellaHipError("cannot load %s: %s" % (LIB_PATH, e)) from e
-    for name, (res, args) in SIGNATURES.items():
+    for name, (res, args) in list(SIGNATURES.items()) + list(TEST_HOOKS.items()):
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch, let it propagate loudly
         fn.restype = res
         fn.argtypes = args
@@ -127,6 +131,17 @@ def check(rc):
 def ptr(t):
     """Device/host pointer of a tensor (or None)."""
     return None if t is None else c_void_p(t.data_ptr())
+
+
+def new_workspace(nbytes, device):
+    """A caller-owned workspace with its ticket header initialised (include/paella_hip.h: paella_workspace_init)."""
+    import torch
+    lib = load()
+    nbytes = max(int(nbytes), int(lib.paella_workspace_header_bytes()))
+    with torch.cuda.device(device):
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        check(lib.paella_workspace_init(ptr(ws), ws.numel(), stream_ptr(device)))
+    return ws
 
 
 def stream_ptr(device=None):

@@ -86,19 +86,22 @@ struct GemmArgs {
 };
 
 // Launchers (each returns PAELLA_OK or an error code; all work is enqueued on `stream`).
-// `ws` is scratch for split-K partial slabs; pass ws_bytes = 0 to forbid split-K.
+// `ws` is a split-K region: kGemmTicketBytes of arrival tickets (zero when first handed to the library -- paella_workspace_init
+// -- and left zero by every launch) followed by slab space for partial tiles; ws_bytes covers both.  ws == nullptr forbids
+// any K split.  One region must not be used by two launches that can run concurrently.
+static const size_t kGemmMaxTickets = (size_t)1 << 16;                       // one ticket per output tile
+static const size_t kGemmTicketBytes = kGemmMaxTickets * sizeof(unsigned);  // 256 KiB header
 int launch_gemm(const GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t stream);
-// Forces a specific tile config / split (for the autotuner and tests). cfg < 0 -> heuristic.
+// Forces a tile config / workgroup count (autotuner and tests). cfg < 0 -> heuristic.  splitk > 0: tiles * splitk workgroups
+// (classic split-K); splitk < 0: exactly -splitk workgroups (balanced contiguous unit ranges).
 int launch_gemm_cfg(const GemmArgs& g, int cfg, int splitk, void* ws, size_t ws_bytes, hipStream_t stream);
-size_t gemm_splitk_ws_bytes(int M, int N, int K);
+int gemm_num_tile_configs();
 // opt-in bf16-operand fast mode (gemm_bf16.hip).  launch_gemm_bf16 returns PAELLA_ERR_STATE when this GEMM has no bf16
 // shadow weight / unsuitable K: the caller falls back to the fp32 kernel.  tile: 0 = 128x128, 1 = 64x64, 2 = 32x32, -1 = choose.
 int launch_gemm_bf16(const GemmArgs& g, int tile, int splitk, void* ws, size_t ws_bytes, hipStream_t stream);
 int gemm_register_weight(const float* base, size_t numel, hipStream_t stream);
 void gemm_unregister_weight(const float* base);
 int gemm_precision();
-// weight-streaming kernel (gemm_ws.hip): tm_code 0..2 -> BM = 16,32,64; nk_code 0..2 -> K-slice capacity 128,192,320; in-launch split-K reduce
-int launch_gemm_ws(const GemmArgs& g, int tm_code, int nk_code, int splitk, void* ws, size_t ws_bytes, hipStream_t stream);
 
 // LayerNorm over the channel dimension of [rows, C]; no learned affine (eps 1e-6),
 // optional scalar affine y = ln(x)*(1+g0)+g1 (VQGAN), optional space-to-depth gather:

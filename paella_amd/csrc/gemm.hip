@@ -8,69 +8,70 @@
 //  * exact-fp32 matrix cores: v_mfma_f32_16x16x4_f32 (bitwise an fmaf chain; 157 TF peak).
 //  * operands are swapped (MFMA "A" = weight rows, "B" = activation rows) so each lane ends up with
 //    4 consecutive output channels -> 16-byte epilogue loads/stores.
-//  * 256-thread workgroups (4 waves), BK = 32, register-prefetched double-buffered LDS,
-//    one barrier per K tile; LDS tiles are [rows][32] floats with the 16-byte column slot XOR-swizzled
-//    by (row & 7): both the staging ds_write_b128 and the fragment ds_read_b128 are conflict-free.
-//  * skinny-M shapes (batch-1 sampling) fill the 256 CUs by deterministic split-K: each K slice writes an
-//    fp32 slab and a second tiny kernel sums the slabs in fixed order and applies the epilogue
-//    (no atomics -> run-to-run bit-reproducible, required for the argmax-parity contract).
-//  * XCD-aware tile order: workgroup b runs on XCD b%8; tiles that share a weight panel are made
-//    consecutive inside one XCD so the panel is fetched from HBM once and re-read from that XCD's L2.
+//  * 4- or 8-wave workgroups, BK = 32, register-prefetched double-buffered LDS, one barrier per K step; LDS tiles are
+//    [rows][32] floats with the 16-byte column slot XOR-swizzled by (row & 7): the staging ds_write_b128 and the
+//    fragment ds_read_b128 are conflict-free.
+//  * ONE work decomposition for every shape ("stream-K"): the launch's work is the sequence of U = tiles x K-steps
+//    units (tile-major, K-step minor); workgroup g of G owns the contiguous range [g*U/G, (g+1)*U/G) and walks it as
+//    ONE prefetch stream, flushing its accumulators whenever the range leaves a tile.
+//      - G = tiles           : classic data-parallel (every workgroup one whole tile), large problems;
+//      - G = tiles * S       : classic split-K;
+//      - any other G         : balanced ranges for skinny problems (batch-1 sampling: M = 32..512 rows against
+//                              1280..5120-wide weights) with tiles that cover all of M, so a weight element is fetched
+//                              from HBM exactly once and the chip is filled by the K split alone.
+//    A tile whose K range is shared by several workgroups is combined deterministically: every part writes an fp32
+//    slab in fragment order (write-through sc1 stores, guide G16 R1), takes a relaxed agent-scope ticket, and the last
+//    arriver sums the parts in FIXED part order and runs the epilogue -- no float atomics, run-to-run bit-reproducible
+//    (the argmax-parity contract needs that).
+//  * tickets live in the caller's workspace header (zeroed once by paella_workspace_init, re-armed by the last
+//    arriver), so they are per workspace = per model / per device / per captured graph.
+//  * XCD-aware workgroup order: workgroup b runs on XCD b%8; logical ids are remapped so that neighbours in unit space
+//    (same tile / same weight panel) share an XCD's L2.
 #include "common.h"
 #include "gemm_device.h"
 #include <stdio.h>
 #include <vector>
 
-#define RET_IF_G(expr) do { int _rc = (expr); if (_rc != PAELLA_OK) return _rc; } while (0)
-
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-// timeline probe (tools/gemm_timeline.py): ABL == 4 builds stamp wall_clock64() (100 MHz) at six points per workgroup
-__device__ unsigned long long* g_trace_ptr = nullptr;
-#define TRACE_STAMP(i)                                                                                                      \
-    do {                                                                                                                    \
-        if constexpr (ABL == 4) {                                                                                           \
-            if (threadIdx.x == 0 && g_trace_ptr) g_trace_ptr[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = wall_clock64(); \
-        }                                                                                                                   \
-    } while (0)
+struct SkPlan {
+    int tiles_m, tiles_n;  // tile grid
+    int KT;                // K steps (of 32) per tile
+    unsigned U;            // tiles_m * tiles_n * KT work units
+};
 
-template <int WM, int WN, int TM, int TN, int PD, int APRO, bool GLDS, int ABL = 0>  // APRO: 0 none, 1 GRN scale/shift, 2 LayerNorm from row statistics
-__global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs g, int kslice, int S, float* __restrict__ slabs,
-                                                               int tiles_m, int tiles_n, unsigned* __restrict__ counters, unsigned slab_bytes) {
+template <int WM, int WN, int TM, int TN, int PD, int APRO>  // APRO: 0 none, 1 GRN scale/shift, 2 LayerNorm from row statistics
+__global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs g, SkPlan p, float* __restrict__ slabs,
+                                                               unsigned* __restrict__ tickets, unsigned slab_bytes) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16, BK = 32;
-    constexpr int NW = WM * WN, NT = 64 * NW;  // 4 waves (256 threads), or 8 waves for the 128x128 tile with 64x32 wave tiles
-    constexpr int RP = NT / 8;                 // rows staged per pass: 8 threads (one float4 each) cover a 32-float row
+    constexpr int NW = WM * WN, NT = 64 * NW;
+    constexpr int RP = NT / 8;  // rows staged per pass: 8 threads (one float4 each) cover a 32-float row
     constexpr int LA = (BM * 8 + NT - 1) / NT, LB = (BN * 8 + NT - 1) / NT;
+    constexpr int TILE_FLOATS = (BM + BN) * BK;
     static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
-    static_assert(NW == 4 || (!GLDS && ABL == 0), "the direct-to-LDS and ablation variants are 4-wave only");
-    constexpr int NSTAGE = GLDS ? PD : 2;  // LDS stages: the GLDS variant uses PD as its LDS ring depth
-    __shared__ __attribute__((aligned(16))) float smem[NSTAGE * (BM + BN) * BK];
+    static_assert(PD == 1 || PD == 2, "prefetch ring depth 1 or 2");
+    // one LDS object: two tile stages + 16 floats for the ticket broadcast (the NEXT unit's tile is already staged when a
+    // segment is flushed, so the flag cannot live inside the stages)
+    __shared__ __attribute__((aligned(16))) float smem[2 * TILE_FLOATS + 16];
 
-    // ---- XCD-aware tile id (bijective remap of blockIdx.x) ----
-    const int nwg = tiles_m * tiles_n;
-    int bid = blockIdx.x;
+    // ---- this workgroup's unit range ----
+    const unsigned G = gridDim.x;
+    unsigned gid = blockIdx.x;
     {
-        const int q = nwg >> 3, r = nwg & 7;
-        const int xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        const unsigned q = G >> 3, r = G & 7;
+        const unsigned xcd = gid & 7, idx = gid >> 3;
+        gid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int tile_m = bid % tiles_m;  // m fastest: neighbours share the weight panel
-    const int tile_n = bid / tiles_m;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int kbeg = blockIdx.y * kslice;
-    const int kend = min(g.K, kbeg + kslice);
+    const unsigned u0 = (unsigned)(((unsigned long long)gid * p.U) / G);
+    const unsigned u1 = (unsigned)(((unsigned long long)(gid + 1) * p.U) / G);
+    const int n = (int)(u1 - u0);
+    if (n <= 0) return;  // host keeps G <= U, so every workgroup owns at least one unit
+    const int KT = p.KT;
 
-    TRACE_STAMP(0);
-    if constexpr (ABL == 4) {  // where did this workgroup run?  slot 6: HW_ID (wave/simd/cu/sh/se), slot 7: XCC_ID
-        if (threadIdx.x == 0 && g_trace_ptr) {
-            unsigned long long* tp = g_trace_ptr + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
-            tp[6] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
-            tp[7] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
-        }
-    }
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int lane_k = tid & 63;
+    const int lane = lane_k;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform -> SGPR arithmetic for wm / wn / slab bases
     const int wm = wave / WN, wn = wave % WN;
     const int r16 = lane & 15, kq = lane >> 4;
     const int ldrow = tid >> 3, ldc4 = tid & 7;
@@ -81,26 +82,49 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs g, int k
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // Global -> register ring -> LDS.  The ring holds PD K-tiles in flight per workgroup: with split-K the K loop of a
-    // workgroup is only 5-10 tiles long and HBM latency (~2k cycles loaded) is several tile-times, so a 1-deep
-    // prefetch leaves the matrix cores waiting.  Loads are unconditional from clamped in-bounds addresses and never
-    // select-masked (a load under a lane condition, or a select on its result inside a conditional block, makes hipcc
-    // wait for it at once); out-of-range rows only feed outputs that are never stored, and the K tail is zeroed on the
-    // ACTIVATION side only when the tile is written to LDS.
-    struct Stage { f32x4 a[LA]; f32x4 s[APRO == 1 ? LA : 1]; f32x4 t; f32x4 b[LB]; };
+    // Global -> register ring -> LDS.  The ring holds PD units in flight per workgroup.  Loads are unconditional from
+    // clamped in-bounds addresses and never select-masked (a load under a lane condition makes hipcc wait for it at
+    // once); out-of-range rows only feed outputs that are never stored, and the K tail is zeroed on the ACTIVATION side
+    // only when the tile is written to LDS.  Everything the LDS store needs travels with the stage, because the load
+    // cursor runs PD units ahead of the compute cursor and may already be in the next tile.
+    struct Stage {
+        f32x4 a[LA];
+        f32x4 s[APRO == 1 ? LA : 1];
+        f32x4 t;
+        f32x4 b[LB];
+        bool kok;
+    };
     Stage R[PD];
+
+    // ---- load cursor ----
+    int ltile = (int)(u0 / (unsigned)KT);
+    int lkt = (int)(u0 - (unsigned)ltile * (unsigned)KT);
     const float* aptr[LA];
     const float* sptr[APRO == 1 ? LA : 1];
     const float* bptr[LB];
     float ln_mu[APRO == 2 ? LA : 1], ln_rs[APRO == 2 ? LA : 1];
+    auto set_tile = [&](int tile) {
+        const int tile_m = tile % p.tiles_m;  // m fastest: consecutive tiles share the weight panel
+        const int tile_n = tile / p.tiles_m;
+        const int m0 = tile_m * BM, n0 = tile_n * BN;
 #pragma unroll
-    for (int i = 0; i < LA; ++i) {
-        const int gmc = min(m0 + ldrow + i * RP, g.M - 1);
-        aptr[i] = g.A + (size_t)gmc * g.lda;
-        if (APRO == 1) sptr[i] = g.a_scale + (size_t)(gmc / g.a_rows_per_sample) * g.K;
-        if (APRO == 2) {
-            // LayerNorm-on-load: combine the producer's per-16-column (sum, sumsq) partials of this row; the 8 lanes that
-            // share the row (tid & 7) split the blocks and xor-reduce.  fp64 for the final E[x^2] - mean^2.
+        for (int i = 0; i < LA; ++i) {
+            const int gmc = min(m0 + ldrow + i * RP, g.M - 1);
+            aptr[i] = g.A + (size_t)gmc * g.lda;
+            if (APRO == 1) sptr[i] = g.a_scale + (size_t)(gmc / g.a_rows_per_sample) * g.K;
+        }
+#pragma unroll
+        for (int i = 0; i < LB; ++i) bptr[i] = g.W + (size_t)min(n0 + ldrow + i * RP, g.N - 1) * g.ldw;
+    };
+    set_tile(ltile);
+    if (APRO == 2) {
+        // LayerNorm-on-load: combine the producer's per-16-column (sum, sumsq) partials of this thread's rows; the 8 lanes that
+        // share a row (tid & 7) split the blocks and xor-reduce.  fp64 for the final E[x^2] - mean^2.  Computed ONCE: the host
+        // only launches this variant with ranges that never change tile_m (tiles_m == 1, or every range inside one tile).
+        const int m0 = (ltile % p.tiles_m) * BM;
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+            const int gmc = min(m0 + ldrow + i * RP, g.M - 1);
             const float* stp = g.ln_stats + (size_t)gmc * g.ln_nblk * 2;
             double s = 0.0, q = 0.0;
             for (int j = ldc4; j < g.ln_nblk; j += 8) { s += (double)stp[2 * j]; q += (double)stp[2 * j + 1]; }
@@ -112,11 +136,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs g, int k
             ln_rs[i] = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + (double)g.ln_eps));
         }
     }
-#pragma unroll
-    for (int i = 0; i < LB; ++i) bptr[i] = g.W + (size_t)min(n0 + ldrow + i * RP, g.N - 1) * g.ldw;
 
-    auto load_tile = [&](Stage& r, int t) {
-        const int kc = min(kbeg + t * BK + ldc4 * 4, g.K - 4);
+    auto load_unit = [&](Stage& r) {  // loads the unit under the load cursor
+        const int kc = min(lkt * BK + ldc4 * 4, g.K - 4);
 #pragma unroll
         for (int i = 0; i < LA; ++i) {
             r.a[i] = *reinterpret_cast<const f32x4*>(aptr[i] + kc);
@@ -125,18 +147,18 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs g, int k
         if (APRO == 1) r.t = *reinterpret_cast<const f32x4*>(g.a_shift + kc);
 #pragma unroll
         for (int i = 0; i < LB; ++i) r.b[i] = *reinterpret_cast<const f32x4*>(bptr[i] + kc);
+        r.kok = lkt * BK + ldc4 * 4 < g.K;
     };
-    auto store_tile_slot = [&](const Stage& r, int t, int slot) {
-        float* As = smem + slot * (BM + BN) * BK;
+    auto store_unit = [&](const Stage& r, int slot) {
+        float* As = smem + slot * TILE_FLOATS;
         float* Bs = As + BM * BK;
-        const bool kok = kbeg + t * BK + ldc4 * 4 < kend;
 #pragma unroll
         for (int i = 0; i < LA; ++i) {
             const int row = ldrow + i * RP;
             f32x4 v = r.a[i];
             if (APRO == 1) v = v * r.s[i] + r.t;
             if (APRO == 2) v = (v - ln_mu[i]) * ln_rs[i];
-            if (!kok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (!r.kok) v = f32x4{0.f, 0.f, 0.f, 0.f};
             if (LA * RP == BM || row < BM) *reinterpret_cast<f32x4*>(As + row * BK + ((ldc4 ^ (row & 7)) << 2)) = v;
         }
 #pragma unroll
@@ -145,53 +167,33 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs g, int k
             if (LB * RP == BN || row < BN) *reinterpret_cast<f32x4*>(Bs + row * BK + ((ldc4 ^ (row & 7)) << 2)) = r.b[i];
         }
     };
-    auto store_tile = [&](const Stage& r, int t) { store_tile_slot(r, t, t & 1); };
-    // All fragment reads of the tile are issued up front (one exposed LDS latency per tile, not one per 16-k group),
-    // and a 1x1 wave tile alternates two accumulators so its MFMAs are never back-to-back dependent
+    // A 1x1 wave tile alternates two accumulators so its MFMAs are never back-to-back dependent
     // (v_mfma_f32_16x16x4_f32: 32-cycle issue, 40-cycle dependent latency).
     constexpr bool DUAL = (TM * TN == 1);
     f32x4 acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto compute = [&](int t) {
-        const float* As = smem + (GLDS ? (t % NSTAGE) : (t & 1)) * (BM + BN) * BK;
+    auto compute = [&](int slot) {
+        const float* As = smem + slot * TILE_FLOATS;
         const float* Bs = As + BM * BK;
-        // small wave tiles and the 8-wave 128x128 configs (2 workgroups of 8 waves per CU: little else hides the LDS latency):
-        // all fragment reads of the tile up front; the other big ones: per 16-k group (VGPRs)
+        // small wave tiles and the 8-wave 128x128 configs: all fragment reads of the tile up front (one exposed LDS latency
+        // per tile); the other big ones: per 16-k group (VGPRs)
         constexpr bool FRAG_FIRST = (TM * TN <= 2) || (NW == 8 && TM + TN <= 6 && PD == 1);
         if constexpr (FRAG_FIRST) {
             f32x4 af[2][TM], bf[2][TN];
-            if (ABL == 3) {  // ablation: MFMA only, operands from registers
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
+            for (int kk = 0; kk < 2; ++kk) {
+                const int c4 = kk * 4 + kq;
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) af[kk][i] = f32x4{1.f, 2.f, 3.f, (float)t};
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) bf[kk][j] = f32x4{1.f, 2.f, (float)t, 4.f};
+                for (int i = 0; i < TM; ++i) {
+                    const int row = (wm * TM + i) * 16 + r16;
+                    af[kk][i] = *reinterpret_cast<const f32x4*>(As + row * BK + ((c4 ^ (row & 7)) << 2));
                 }
-            } else {
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    const int c4 = kk * 4 + kq;
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) {
-                        const int row = (wm * TM + i) * 16 + r16;
-                        af[kk][i] = *reinterpret_cast<const f32x4*>(As + row * BK + ((c4 ^ (row & 7)) << 2));
-                    }
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        const int row = (wn * TN + j) * 16 + r16;
-                        bf[kk][j] = *reinterpret_cast<const f32x4*>(Bs + row * BK + ((c4 ^ (row & 7)) << 2));
-                    }
+                for (int j = 0; j < TN; ++j) {
+                    const int row = (wn * TN + j) * 16 + r16;
+                    bf[kk][j] = *reinterpret_cast<const f32x4*>(Bs + row * BK + ((c4 ^ (row & 7)) << 2));
                 }
             }
-            if (ABL == 1) {  // ablation: no MFMA, keep the fragment reads alive
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(af[kk][i]));
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(bf[kk][j]));
-                }
-            } else if (DUAL) {
+            if (DUAL) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[0][0][e], af[0][0][e], acc[0][0], 0, 0, 0);
@@ -223,399 +225,259 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs g, int k
                     const int row = (wn * TN + j) * 16 + r16;
                     bf[j] = *reinterpret_cast<const f32x4*>(Bs + row * BK + ((c4 ^ (row & 7)) << 2));
                 }
-                if (ABL == 1) {
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(af[i]));
+                for (int e = 0; e < 4; ++e)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(bf[j]));
-                } else {
+                    for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][e], af[i][e], acc[i][j], 0, 0, 0);
+            }
+        }
+    };
+
+    // ---- epilogue of a finished tile: lane holds out[m = ..+r16][n = ..+kq*4 .. +3] ----
+    auto epilogue = [&](int m0, int n0, int r16, int kq) {
 #pragma unroll
-                        for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + (wm * TM + i) * 16 + r16;
 #pragma unroll
-                            for (int j = 0; j < TN; ++j)
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][e], af[i][e], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < TN; ++j) {
+                const int nn = n0 + (wn * TN + j) * 16 + kq * 4;
+                const bool ok = m < g.M && nn < g.N;
+                f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (ok) {
+                    v = epilogue_apply(g.ep, g.N, m, nn, acc[i][j]);
+                    epilogue_write(g.ep, g.C, g.ldc, m, nn, v);
+                }
+                if (g.ep.sumsq_out) {  // kernel-uniform: per-16-row column sums of squares (GlobalResponseNorm statistics)
+                    f32x4 q = v * v;
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1) {
+                        q[0] += __shfl_xor(q[0], o, 64);
+                        q[1] += __shfl_xor(q[1], o, 64);
+                        q[2] += __shfl_xor(q[2], o, 64);
+                        q[3] += __shfl_xor(q[3], o, 64);
+                    }
+                    const int mg = m0 + (wm * TM + i) * 16;
+                    if (r16 == 0 && nn < g.N && mg < g.M) *reinterpret_cast<f32x4*>(g.ep.sumsq_out + (size_t)(mg >> 4) * g.N + nn) = q;
+                }
+                if (g.ep.rowstat_out) {  // kernel-uniform: per-row (sum, sum of squares) over this 16-column block (LayerNorm-on-load)
+                    float rs = (v[0] + v[1]) + (v[2] + v[3]);
+                    float rq = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                    rs += __shfl_xor(rs, 16, 64); rq += __shfl_xor(rq, 16, 64);
+                    rs += __shfl_xor(rs, 32, 64); rq += __shfl_xor(rq, 32, 64);
+                    const int nb = n0 + (wn * TN + j) * 16;
+                    if (kq == 0 && m < g.M && nb < g.N) {
+                        float* dstp = g.ep.rowstat_out + ((size_t)m * (g.N >> 4) + (nb >> 4)) * 2;
+                        dstp[0] = rs; dstp[1] = rq;
+                    }
                 }
             }
         }
     };
 
-    const int ntiles = (kend - kbeg + BK - 1) / BK;
-    if constexpr (GLDS) {
-        // Direct global -> LDS DMA (global_load_lds_dwordx4): no VGPR staging and, above all, no ds_write_b128 (13 LDS-pipe
-        // cycles per wave-instruction -- for 32x32 tiles the LDS pipe, not the matrix cores, was the busiest unit).
-        // The LDS image of a wave's DMA is lane-linear (8 rows x 128 B), so the XOR swizzle is applied to the SOURCE
-        // chunk each lane fetches (guide rule 21); a row's 128-byte line is still fetched whole -> coalescing unchanged.
-        // Requires K % 32 == 0 (no tail masking), no A prologue, BM and BN multiples of 32 -- checked by the launcher.
-        const int swz = (tid & 7) ^ ((tid >> 3) & 7);
-        auto glds_tile = [&](int t) {
-            float* As = smem + (t % NSTAGE) * (BM + BN) * BK;
-            float* Bs = As + BM * BK;
-            const int kc = min(kbeg + t * BK, g.K - BK) + swz * 4;
-#pragma unroll
-            for (int i = 0; i < LA; ++i)
-                __builtin_amdgcn_global_load_lds((const void*)(aptr[i] + kc),
-                                                 (__attribute__((address_space(3))) void*)(As + (wave * 8 + i * 32) * BK), 16, 0, 0);
-#pragma unroll
-            for (int i = 0; i < LB; ++i)
-                __builtin_amdgcn_global_load_lds((const void*)(bptr[i] + kc),
-                                                 (__attribute__((address_space(3))) void*)(Bs + (wave * 8 + i * 32) * BK), 16, 0, 0);
-        };
-        // NSTAGE-deep LDS ring, NSTAGE-1 tiles of DMA in flight across the (raw) barrier: counted vmcnt, never 0 in the loop
-        // (guide 5 "Pipelining across barriers": __syncthreads() would drain the DMA queue, s_barrier does not).
-#pragma unroll
-        for (int j = 0; j < NSTAGE - 1; ++j) glds_tile(j);
-        for (int t = 0; t < ntiles; ++t) {
-            // tile t has landed once at most NSTAGE-2 younger tiles (LA+LB DMA instructions each) are still outstanding
-            if constexpr ((NSTAGE - 2) * (LA + LB) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if constexpr ((NSTAGE - 2) * (LA + LB) == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else if constexpr ((NSTAGE - 2) * (LA + LB) == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            else if constexpr ((NSTAGE - 2) * (LA + LB) == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else if constexpr ((NSTAGE - 2) * (LA + LB) == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else if constexpr ((NSTAGE - 2) * (LA + LB) == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();          // every wave's share of tile t is in LDS; every wave is done with tile t-1
-            glds_tile(t + NSTAGE - 1);             // refill the stage tile t-1 occupied
-            compute(t);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    } else {
-    // invariant at the top of iteration t: tile t is in LDS[t&1]; R[(t+1)%PD .. (t+PD-1)%PD] hold tiles t+1..t+PD-1; R[t%PD] is free
-#pragma unroll
-    for (int j = 0; j < PD; ++j) load_tile(R[j], j);
-    store_tile(R[0], 0);
-    __syncthreads();
-    TRACE_STAMP(1);
-    int t = 0;
-    for (; t + PD <= ntiles; t += PD) {  // full chunks: no per-tile conditionals, one basic block per tile
-#pragma unroll
-        for (int u = 0; u < PD; ++u) {
-            if (ABL != 2) load_tile(R[u], t + u + PD);
-            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch above the MFMA block (hipcc sinks it otherwise)
-            compute(t + u);
-            __builtin_amdgcn_sched_barrier(0);
-            if (ABL != 2) store_tile(R[(u + 1) % PD], t + u + 1);
-            __syncthreads();
-        }
-    }
-    const int rem = ntiles - t;  // < PD tiles left: tile t is in LDS, t+1.. are in R[1..]
-#pragma unroll
-    for (int u = 0; u < PD - 1; ++u) {
-        if (u < rem) {
-            compute(t + u);
-            if (u + 1 < rem) store_tile(R[(u + 1) % PD], t + u + 1);
-            __syncthreads();
-        }
-    }
-    }
-
-    if (DUAL) acc[0][0] += acc2;
-    TRACE_STAMP(2);
-
-    // ---- split-K: write this slice's fp32 slab in fragment order (fully coalesced); splitk_reduce_frag_kernel sums the
-    // slabs in fixed slice order and runs the epilogue.  (An in-launch "last arriver" combine was measured 1.7x SLOWER
-    // end to end here: every workgroup pays an agent-scope release fence of several us -- see DESIGN.md.) ----
-    if (S > 1) {
-        constexpr int FR = TM * TN * 64 * 4;  // floats per wave, fragment order [i][j][lane][4]
-        if (!counters) {  // two-launch mode: splitk_reduce_frag_kernel combines
-            float* my = slabs + ((size_t)bid * S + blockIdx.y) * (NW * FR) + (size_t)wave * FR;
+    // ---- end of a segment (the unit range left the tile, or ended): K steps [k0, k1) of `tile` are in the accumulators ----
+    constexpr int FR = TM * TN * 64 * 4;                     // floats per wave, fragment order [i][j][lane][4]
+    constexpr unsigned SLOT_BYTES = (unsigned)(NW * FR * 4);  // one slab = one tile of fp32 partial sums
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(slabs, 0, (int)slab_bytes, 0x00020000);
+    auto flush = [&](int tile, int k0, int k1, bool first) {
+        const int tile_m = tile % p.tiles_m, tile_n = tile / p.tiles_m;
+        // launder the lane id: everything the flush derives from it (fragment offsets, output rows / columns, masks) would
+        // otherwise be hoisted out of the unit loop and held in ~80 VGPRs across the MFMA stream
+        int lane = lane_k;
+        asm volatile("" : "+v"(lane));
+        const int r16 = lane & 15, kq = lane >> 4;
+        if (DUAL) { acc[0][0] += acc2; acc2 = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        bool finish = true;
+        if (!(k0 == 0 && k1 == KT)) {
+            // Partial tile.  Slab slots are per workgroup: 2*gid for a segment that starts this workgroup's range ("head"),
+            // 2*gid + 1 for a later one (necessarily its last).  Write-through (sc1) stores, every storing wave drains
+            // vmcnt(0), ONE lane takes a relaxed agent-scope ticket; the last arriver reads all parts back with sc1 loads
+            // (no fences, guide G16 recipe R1) in FIXED part order g_first..g_last.
+            const unsigned mybase = (2u * gid + (first ? 0u : 1u)) * SLOT_BYTES + (unsigned)(wave * FR * 4);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) *reinterpret_cast<f32x4*>(my + ((i * TN + j) * 64 + lane) * 4) = acc[i][j];
-            return;
+                for (int j = 0; j < TN; ++j)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rsrc,
+                                                           mybase + ((i * TN + j) * 64 + lane) * 16, 0, 16);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            unsigned* sflag = reinterpret_cast<unsigned*>(smem + 2 * TILE_FLOATS);
+            if (tid == 0) sflag[0] = __hip_atomic_fetch_add(tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            // the workgroups whose ranges intersect this tile's units [tb, tb + KT): start(g) = floor(g*U/G) is strictly increasing
+            const unsigned long long tb = (unsigned long long)tile * (unsigned)KT;
+            const unsigned g_first = (unsigned)(((tb + 1) * G - 1) / p.U);
+            const unsigned g_last = (unsigned)(((tb + (unsigned)KT) * G - 1) / p.U);
+            finish = sflag[0] == g_last - g_first;
+            if (finish) {
+                if (tid == 0) __hip_atomic_store(tickets + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
+                const unsigned long long start_first = ((unsigned long long)g_first * p.U) / G;
+                const unsigned off_first = (2u * g_first + (start_first < tb ? 1u : 0u)) * SLOT_BYTES;  // g_first came from an earlier tile -> its tail slot
+                const unsigned wbase = (unsigned)(wave * FR * 4);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const unsigned fo = wbase + ((i * TN + j) * 64 + lane) * 16;
+                        f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off_first + fo, 0, 16));
+                        unsigned gp = g_first + 1;
+                        for (; gp + 3 <= g_last; gp += 4) {  // 4 loads in flight, added in part order
+                            const f32x4 a0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (2u * gp + 0u) * SLOT_BYTES + fo, 0, 16));
+                            const f32x4 a1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (2u * gp + 2u) * SLOT_BYTES + fo, 0, 16));
+                            const f32x4 a2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (2u * gp + 4u) * SLOT_BYTES + fo, 0, 16));
+                            const f32x4 a3 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (2u * gp + 6u) * SLOT_BYTES + fo, 0, 16));
+                            v += a0; v += a1; v += a2; v += a3;
+                        }
+                        for (; gp <= g_last; ++gp)
+                            v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, 2u * gp * SLOT_BYTES + fo, 0, 16));
+                        acc[i][j] = v;
+                    }
+            }
         }
-        // In-launch combine, write-through form (guide section 6 G16 recipe R1): slabs are stored with sc1 (agent-scope,
-        // write-through) so no release fence is needed; every storing wave drains vmcnt(0), ONE lane takes a relaxed
-        // agent-scope ticket; the last arriver reads all slabs back with sc1 loads (no acquire fence) in FIXED slice order.
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(slabs, 0, (int)slab_bytes, 0x00020000);
-        const unsigned mybase = (unsigned)((((size_t)bid * S + blockIdx.y) * (NW * FR) + (size_t)wave * FR) * sizeof(float));
+        if (finish) epilogue(tile_m * BM, tile_n * BN, r16, kq);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rsrc,
-                                                       mybase + ((i * TN + j) * 64 + lane) * 16, 0, 16);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        TRACE_STAMP(3);
-        unsigned* sflag = reinterpret_cast<unsigned*>(smem);
-        if (tid == 0) sflag[0] = __hip_atomic_fetch_add(counters + bid, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        TRACE_STAMP(4);
-        if (sflag[0] != (unsigned)(S - 1)) return;
-        if (tid == 0) __hip_atomic_store(counters + bid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
-        const unsigned tbase = (unsigned)(((size_t)bid * S * (NW * FR) + (size_t)wave * FR) * sizeof(float));
-        const unsigned sstride = (unsigned)(NW * FR * sizeof(float));
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const unsigned off = tbase + ((i * TN + j) * 64 + lane) * 16;
-                f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 16));
-                int s = 1;
-                for (; s + 3 < S; s += 4) {
-                    const f32x4 a0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + (s + 0) * sstride, 0, 16));
-                    const f32x4 a1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + (s + 1) * sstride, 0, 16));
-                    const f32x4 a2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + (s + 2) * sstride, 0, 16));
-                    const f32x4 a3 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + (s + 3) * sstride, 0, 16));
-                    v += a0; v += a1; v += a2; v += a3;
-                }
-                for (; s < S; ++s) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + s * sstride, 0, 16));
-                acc[i][j] = v;
-            }
-    }
+            for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
 
-    // ---- epilogue: lane holds out[m = ..+r16][n = ..+kq*4 .. +3] ----
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = m0 + (wm * TM + i) * 16 + r16;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + (wn * TN + j) * 16 + kq * 4;
-            const bool ok = m < g.M && n < g.N;
-            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (ok) {
-                v = epilogue_apply(g.ep, g.N, m, n, acc[i][j]);
-                epilogue_write(g.ep, g.C, g.ldc, m, n, v);
-            }
-            if (g.ep.sumsq_out) {  // kernel-uniform: per-16-row column sums of squares (GlobalResponseNorm statistics)
-                f32x4 q = v * v;
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    q[0] += __shfl_xor(q[0], o, 64);
-                    q[1] += __shfl_xor(q[1], o, 64);
-                    q[2] += __shfl_xor(q[2], o, 64);
-                    q[3] += __shfl_xor(q[3], o, 64);
-                }
-                const int mg = m0 + (wm * TM + i) * 16;
-                if (r16 == 0 && n < g.N && mg < g.M) *reinterpret_cast<f32x4*>(g.ep.sumsq_out + (size_t)(mg >> 4) * g.N + n) = q;
-            }
-            if (g.ep.rowstat_out) {  // kernel-uniform: per-row (sum, sum of squares) over this 16-column block (LayerNorm-on-load)
-                float rs = (v[0] + v[1]) + (v[2] + v[3]);
-                float rq = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-                rs += __shfl_xor(rs, 16, 64); rq += __shfl_xor(rq, 16, 64);
-                rs += __shfl_xor(rs, 32, 64); rq += __shfl_xor(rq, 32, 64);
-                const int nb = n0 + (wn * TN + j) * 16;
-                if (kq == 0 && m < g.M && nb < g.N) {
-                    float* dstp = g.ep.rowstat_out + ((size_t)m * (g.N >> 4) + (nb >> 4)) * 2;
-                    dstp[0] = rs; dstp[1] = rq;
-                }
-            }
+    // ---- the unit stream ----
+    // invariant at the top of unit i: unit i is in LDS[slot]; R[(i+1)%PD .. (i+PD-1)%PD] hold units i+1..i+PD-1; R[i%PD] is free
+    int loaded = 0;  // units fetched so far; the load cursor stops on the range's last unit (re-reading it hits L1/L2)
+    auto fetch = [&](Stage& r) {
+        load_unit(r);
+        if (++loaded < n && ++lkt == KT) {  // workgroup-uniform; never runs into the next workgroup's units
+            lkt = 0;
+            ++ltile;
+            set_tile(ltile);
         }
-    }
-    if constexpr (ABL == 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    TRACE_STAMP(5);
-}
+    };
+#pragma unroll
+    for (int j = 0; j < PD; ++j) fetch(R[j]);
+    store_unit(R[0], 0);
+    __syncthreads();
 
-// Split-K reducer: one workgroup per output tile, same thread -> element mapping as gemm_nt_kernel, so every slab
-// load is a coalesced 1 KiB wave access and the epilogue (incl. the GRN column sums of squares) is shared code.
-template <int WM, int WN, int TM, int TN>
-__global__ __launch_bounds__(64 * WM * WN) void splitk_reduce_frag_kernel(GemmArgs g, int S, const float* __restrict__ slabs,
-                                                                 int tiles_m, int tiles_n) {
-    constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
-    constexpr int FR = TM * TN * 64 * 4;
-    constexpr int NW = WM * WN;
-    const int bid = blockIdx.x;  // already the remapped tile id used by the producer
-    const int tile_m = bid % tiles_m, tile_n = bid / tiles_m;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int r16 = lane & 15, kq = lane >> 4;
-    const float* base = slabs + (size_t)bid * S * (NW * FR) + (size_t)wave * FR;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = m0 + (wm * TM + i) * 16 + r16;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const float* p = base + ((i * TN + j) * 64 + lane) * 4;
-            f32x4 acc = *reinterpret_cast<const f32x4*>(p);
-            int s = 1;
-            for (; s + 3 < S; s += 4) {  // 4 loads in flight, added in slice order
-                const f32x4 a0 = *reinterpret_cast<const f32x4*>(p + (size_t)(s + 0) * (NW * FR));
-                const f32x4 a1 = *reinterpret_cast<const f32x4*>(p + (size_t)(s + 1) * (NW * FR));
-                const f32x4 a2 = *reinterpret_cast<const f32x4*>(p + (size_t)(s + 2) * (NW * FR));
-                const f32x4 a3 = *reinterpret_cast<const f32x4*>(p + (size_t)(s + 3) * (NW * FR));
-                acc += a0; acc += a1; acc += a2; acc += a3;
+    int ctile = (int)(u0 / (unsigned)KT);
+    int ckt = (int)(u0 - (unsigned)ctile * (unsigned)KT);
+    bool first_seg = true;
+    int slot = 0;
+    int ph = 0;  // i % PD
+    for (int i = 0; i < n;) {
+        const int seg_len = min(KT - ckt, n - i);
+        for (int s = 0; s < seg_len; ++s) {
+            // one basic block per unit: the prefetch is pinned above the MFMA block (hipcc sinks it otherwise)
+            if (PD == 1 || ph == 0) {
+                fetch(R[0]);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(slot);
+                __builtin_amdgcn_sched_barrier(0);
+                store_unit(R[1 % PD], slot ^ 1);
+            } else {
+                fetch(R[PD - 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(slot);
+                __builtin_amdgcn_sched_barrier(0);
+                store_unit(R[0], slot ^ 1);
             }
-            for (; s < S; ++s) acc += *reinterpret_cast<const f32x4*>(p + (size_t)s * (NW * FR));
-            const int n = n0 + (wn * TN + j) * 16 + kq * 4;
-            const bool ok = m < g.M && n < g.N;
-            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (ok) {
-                v = epilogue_apply(g.ep, g.N, m, n, acc);
-                epilogue_write(g.ep, g.C, g.ldc, m, n, v);
-            }
-            if (g.ep.sumsq_out) {
-                f32x4 q = v * v;
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    q[0] += __shfl_xor(q[0], o, 64);
-                    q[1] += __shfl_xor(q[1], o, 64);
-                    q[2] += __shfl_xor(q[2], o, 64);
-                    q[3] += __shfl_xor(q[3], o, 64);
-                }
-                const int mg = m0 + (wm * TM + i) * 16;
-                if (r16 == 0 && n < g.N && mg < g.M) *reinterpret_cast<f32x4*>(g.ep.sumsq_out + (size_t)(mg >> 4) * g.N + n) = q;
-            }
-            if (g.ep.rowstat_out) {  // kernel-uniform: per-row (sum, sum of squares) over this 16-column block (LayerNorm-on-load)
-                float rs = (v[0] + v[1]) + (v[2] + v[3]);
-                float rq = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-                rs += __shfl_xor(rs, 16, 64); rq += __shfl_xor(rq, 16, 64);
-                rs += __shfl_xor(rs, 32, 64); rq += __shfl_xor(rq, 32, 64);
-                const int nb = n0 + (wn * TN + j) * 16;
-                if (kq == 0 && m < g.M && nb < g.N) {
-                    float* dstp = g.ep.rowstat_out + ((size_t)m * (g.N >> 4) + (nb >> 4)) * 2;
-                    dstp[0] = rs; dstp[1] = rq;
-                }
-            }
+            __syncthreads();
+            slot ^= 1;
+            ph = (PD == 1) ? 0 : (ph ^ 1);
         }
+        flush(ctile, ckt, ckt + seg_len, first_seg);
+        first_seg = false;
+        i += seg_len;
+        ckt += seg_len;
+        if (ckt == KT) { ckt = 0; ++ctile; }
     }
 }
 
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
-struct TileCfg { int wm, wn, tm, tn; };
+struct TileCfg { int wm, wn, tm, tn, pd; };
+// BM = wm*tm*16, BN = wn*tn*16; ids are stable (tests and tools name them)
 static const TileCfg kCfgs[] = {
-    {2, 2, 4, 4},  // 0: 128x128
-    {2, 2, 4, 2},  // 1: 128x64
-    {2, 2, 2, 2},  // 2: 64x64
-    {2, 2, 2, 1},  // 3: 64x32
-    {2, 2, 1, 2},  // 4: 32x64
-    {2, 2, 1, 1},  // 5: 32x32
-    {1, 4, 1, 1},  // 6: 16x64
-    {1, 4, 1, 2},  // 7: 16x128
-    {1, 4, 2, 2},  // 8: 32x128
-    {2, 4, 4, 2},  // 9: 128x128, 8 waves (64x32 wave tiles): the big tile's operand reuse at twice its occupancy
-    {4, 2, 2, 4},  // 10: 128x128, 8 waves (32x64 wave tiles)
-    {2, 4, 2, 2},  // 11: 64x128, 8 waves
-    {4, 2, 2, 2},  // 12: 128x64, 8 waves
-    {2, 4, 4, 2},  // 13: = 9, fragment-first
-    {4, 2, 2, 4},  // 14: = 10, fragment-first
+    {2, 2, 4, 4, 1},  // 0: 128x128
+    {2, 2, 4, 2, 2},  // 1: 128x64
+    {2, 2, 2, 2, 2},  // 2: 64x64
+    {2, 2, 2, 1, 2},  // 3: 64x32
+    {2, 2, 1, 2, 2},  // 4: 32x64
+    {2, 2, 1, 1, 2},  // 5: 32x32
+    {1, 4, 1, 1, 2},  // 6: 16x64
+    {1, 4, 1, 2, 2},  // 7: 16x128
+    {1, 4, 2, 2, 2},  // 8: 32x128
+    {4, 2, 2, 4, 1},  // 9: 128x128, 8 waves (32x64 wave tiles, fragment-first): the large-problem default
+    {2, 4, 4, 2, 1},  // 10: 128x128, 8 waves (64x32 wave tiles, fragment-first)
+    {4, 1, 2, 2, 2},  // 11: 128x32, waves stacked along M (32x32 wave tiles): M-covering for M <= 128
+    {4, 1, 2, 4, 2},  // 12: 128x64, waves stacked along M (32x64 wave tiles)
+    {4, 1, 1, 4, 2},  // 13: 64x64, waves stacked along M (16x64 wave tiles): M-covering for M <= 64
+    {4, 2, 2, 2, 2},  // 14: 128x64, 8 waves (32x32 wave tiles)
+    {8, 1, 2, 2, 2},  // 15: 256x32, 8 waves stacked along M
+    {8, 1, 2, 4, 1},  // 16: 256x64, 8 waves stacked along M (32x64 wave tiles)
+    {8, 1, 1, 4, 2},  // 17: 128x64, 8 waves stacked along M (16x64 wave tiles)
+    {2, 2, 2, 2, 1},  // 18: 64x64, 1-deep prefetch
+    {2, 2, 1, 1, 1},  // 19: 32x32, 1-deep prefetch
+    {4, 1, 2, 4, 1},  // 20: 128x64 stacked, 1-deep prefetch
+    {4, 1, 1, 2, 2},  // 21: 64x32, waves stacked along M (16x32 wave tiles)
+    {2, 2, 1, 4, 2},  // 22: 32x128 (16x64 wave tiles): M-covering for M <= 32
+    {1, 4, 2, 1, 2},  // 23: 32x64, waves along N (32x16 wave tiles)
 };
 static const int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
-
-// Workgroup spreading: the hardware dispatcher packs workgroups onto a CU up to its occupancy limit before moving on,
-// so a 640-workgroup grid of small tiles lands on ~1/3 of the 256 CUs (measured: SQ_BUSY_CU_CYCLES = 64 % of the
-// kernel, every tile config ~26 us where the matrix-core floor is 11 us).  Reserving unused dynamic LDS caps the
-// workgroups per CU at ceil(grid / 256) so a sub-capacity grid spreads over the whole chip.
-static int g_spread = 0;
-int gemm_tile_counters(unsigned** out, hipStream_t st);
-static int g_combine = 1;  // in-launch split-K combine with write-through (sc1) slabs
-static int g_glds = 0;  // measured neutral-to-negative on MI355X for these shapes (tools/gemm_warm_cold.py); kept for A/B
-// debug switches for A/B measurements: bit 0 = workgroup spreading (LDS reservation), bit 1 = direct global->LDS staging
-// bit 2 (value 4) = DISABLE the in-launch split-K combine (use the two-launch reducer)
-extern "C" int paella_debug_set_trace(void* dev_buf) {
-    unsigned long long* p = reinterpret_cast<unsigned long long*>(dev_buf);
-    HIP_CHECK_RET(hipMemcpyToSymbol(HIP_SYMBOL(g_trace_ptr), &p, sizeof(p)));
-    return PAELLA_OK;
-}
-extern "C" int paella_debug_set_spread(int on) { g_spread = on & 1; g_glds = (on >> 1) & 1; g_combine = ((on >> 2) & 1) ? 0 : 1; return PAELLA_OK; }
+int gemm_num_tile_configs() { return kNumCfgs; }
 
 template <int WM, int WN, int TM, int TN, int PD>
-static void launch_one(const GemmArgs& g, int kslice, int S, float* slabs, hipStream_t st) {
-    constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+static void launch_one(const GemmArgs& g, const SkPlan& p, unsigned G, float* slabs, unsigned* tickets, unsigned slab_bytes, hipStream_t st) {
     constexpr int NT = 64 * WM * WN;
-    constexpr int kStaticLds = 2 * (BM + BN) * 32 * 4;
-    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
-    dim3 grid(tiles_m * tiles_n, S);
-    const long wgs = (long)tiles_m * tiles_n * S;
-    size_t pad = 0;
-    if (g_spread) {
-        const long per_cu = (wgs + 255) / 256;
-        if (per_cu < 8) {
-            const size_t want = (size_t)(160 * 1024) / (size_t)per_cu - 512;  // LDS per workgroup that admits exactly per_cu of them
-            if (want > (size_t)kStaticLds) pad = (want - kStaticLds) & ~(size_t)255;
-            if (kStaticLds + pad > 64 * 1024) pad = 64 * 1024 - kStaticLds;   // stay within the default 64 KiB launch limit
-        }
-    }
-    constexpr bool kCanGlds = NT == 256 && (BM % 32 == 0) && (BN % 32 == 0);
-    const bool glds = kCanGlds && g_glds && !g.a_scale && !g.ln_stats && (g.K % 32 == 0) && g.K >= 32;
-    unsigned* counters = nullptr;
-    const size_t slab_bytes = (size_t)tiles_m * tiles_n * S * BM * BN * sizeof(float);
-    if (S > 1 && g_combine && slab_bytes < ((size_t)1 << 31)) (void)gemm_tile_counters(&counters, st);
     if (g.a_scale)
-        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, PD, 1, false>), grid, dim3(NT), pad, st, g, kslice, S, slabs, tiles_m, tiles_n, counters, (unsigned)slab_bytes);
+        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, PD, 1>), dim3(G), dim3(NT), 0, st, g, p, slabs, tickets, slab_bytes);
     else if (g.ln_stats)
-        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, PD, 2, false>), grid, dim3(NT), pad, st, g, kslice, S, slabs, tiles_m, tiles_n, counters, (unsigned)slab_bytes);
-    else if (glds)
-        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, (BM + BN <= 64 ? 4 : (BM + BN <= 128 ? 3 : 2)), 0, kCanGlds>), grid, dim3(NT), pad, st, g, kslice, S, slabs, tiles_m, tiles_n, counters, (unsigned)slab_bytes);
+        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, PD, 2>), dim3(G), dim3(NT), 0, st, g, p, slabs, tickets, slab_bytes);
     else
-        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, PD, 0, false>), grid, dim3(NT), pad, st, g, kslice, S, slabs, tiles_m, tiles_n, counters, (unsigned)slab_bytes);
-    if (S > 1 && !counters)
-        hipLaunchKernelGGL((splitk_reduce_frag_kernel<WM, WN, TM, TN>), dim3(tiles_m * tiles_n), dim3(NT), 0, st, g, S, slabs, tiles_m, tiles_n);
+        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, PD, 0>), dim3(G), dim3(NT), 0, st, g, p, slabs, tickets, slab_bytes);
 }
 
-// Split-K ticket counters (one word per output tile, zero between launches).  Launches on DIFFERENT streams may run
-// concurrently, so every stream gets its own block out of a small pool allocated once (no allocation later: the first
-// launch on a new stream may already be under stream capture).  More than kPoolBlocks concurrent streams share blocks.
-static unsigned* g_counter_pool = nullptr;
-static const int kMaxTiles = 1 << 16;
-static const int kPoolBlocks = 8;
-static std::vector<hipStream_t> g_pool_streams;
-int gemm_tile_counters(unsigned** out, hipStream_t st) {
-    if (!g_counter_pool) {
-        HIP_CHECK_RET(hipMalloc((void**)&g_counter_pool, (size_t)kPoolBlocks * kMaxTiles * sizeof(unsigned)));
-        HIP_CHECK_RET(hipMemset(g_counter_pool, 0, (size_t)kPoolBlocks * kMaxTiles * sizeof(unsigned)));
-        HIP_CHECK_RET(hipDeviceSynchronize());
-    }
-    size_t idx = 0;
-    for (; idx < g_pool_streams.size(); ++idx)
-        if (g_pool_streams[idx] == st) break;
-    if (idx == g_pool_streams.size()) {
-        if (g_pool_streams.size() < (size_t)kPoolBlocks) g_pool_streams.push_back(st);
-        else idx = ((size_t)(uintptr_t)st >> 4) % kPoolBlocks;
-    }
-    *out = g_counter_pool + idx * kMaxTiles;
-    return PAELLA_OK;
-}
-int gemm_max_tiles() { return kMaxTiles; }
-
-size_t gemm_splitk_ws_bytes(int M, int N, int K) {
-    (void)K;
-    return (size_t)16 * M * N * sizeof(float);  // up to 16 slabs
+static inline long tiles_of_cfg(int c, int M, int N) {
+    const int BM = kCfgs[c].wm * kCfgs[c].tm * 16, BN = kCfgs[c].wn * kCfgs[c].tn * 16;
+    return (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
 }
 
-// Tile / split-K choice, fitted to tools/gemm_tune.py sweeps on MI355X (profiles/r01_gemm_tile_split_sweep*.txt).
-// What the sweeps show: a lone workgroup needs ~0.35 us per K-tile with 32x32 tiles (~0.73 us with 64x64) no matter
-// how idle the chip is (load -> LDS -> barrier -> MFMA chain), so skinny problems want SHORT K loops (10-20 tiles per
-// workgroup, via split-K) and at least ~320 workgroups; once >= ~1000 workgroups exist the 64x64 tile is the most
-// efficient (85-90 % of the matrix-core rate at the sustained clock) and splitting only costs slab traffic.
-static void choose_config(int M, int N, int K, size_t ws_bytes, int* cfg_out, int* split_out) {
-    auto tiles_of = [&](int c) {
-        const int BM = kCfgs[c].wm * kCfgs[c].tm * 16, BN = kCfgs[c].wn * kCfgs[c].tn * 16;
-        return (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-    };
+// Tile / workgroup-count choice, fitted to tools/gemm_tune.py sweeps on MI355X (profiles/r02_gemm_tile_sweep*.txt).
+// Returns the tile config and G (number of workgroups = number of contiguous unit ranges).
+static void choose_config(int M, int N, int K, size_t slab_cap_bytes, int* cfg_out, unsigned* G_out) {
     const int ktiles = (K + 31) / 32;
-    int cfg, S = 1;
     const double macs = (double)M * N * K;
-    if (tiles_of(0) >= 1024) {  // >= 4 workgroups of 128x128 per CU: the big tile with 8 waves (32x64 wave tiles) wins at any K (121-128 TF)
-        cfg = 14;
-    } else if (tiles_of(2) >= 1024 || macs >= 3e9) {  // big problems: 64x64 tiles, split only to reach ~1024 workgroups
+    int cfg;
+    long S = 1;
+    if (tiles_of_cfg(0, M, N) >= 1024) {  // >= 4 workgroups of 128x128 per CU: the big tile with 8 waves (32x64 wave tiles) wins at any K
+        cfg = 9;
+    } else if (tiles_of_cfg(2, M, N) >= 1024 || macs >= 3e9) {  // big problems: 64x64 tiles, split only to reach ~1024 workgroups
         cfg = 2;
-        const long t = tiles_of(2);
+        const long t = tiles_of_cfg(2, M, N);
         while (t * S < 1024 && S < 16 && ktiles / (S * 2) >= 5) S *= 2;
-    } else {                                          // skinny: 32x32 tiles, K loop <= 20 tiles, >= 512 workgroups
+    } else {                                                     // skinny: 32x32 tiles, K loop <= 20 tiles, >= 512 workgroups
         cfg = 5;
-        const long t = tiles_of(5);
+        const long t = tiles_of_cfg(5, M, N);
         if (t < 1024) {
             while (ktiles / S > 20 && S < 16) S *= 2;
             while (t * S < (t >= 512 ? 1024 : 512) && S < 16 && ktiles / (S * 2) >= 5) S *= 2;
             while (S > 1 && t * S > 2560) S /= 2;
         }
     }
-    // workspace / tile-count limits
-    for (;;) {
-        const int BM = kCfgs[cfg].wm * kCfgs[cfg].tm * 16, BN = kCfgs[cfg].wn * kCfgs[cfg].tn * 16;
-        if (S == 1 || ((size_t)S * tiles_of(cfg) * BM * BN * 4 <= ws_bytes && tiles_of(cfg) <= kMaxTiles)) break;
-        S /= 2;
+    long G = tiles_of_cfg(cfg, M, N) * S;
+    const long U = tiles_of_cfg(cfg, M, N) * ktiles;
+    if (G > U) G = U;
+    // workspace limits: partial tiles need 2 slab slots per workgroup and one ticket per tile
+    const int BM = kCfgs[cfg].wm * kCfgs[cfg].tm * 16, BN = kCfgs[cfg].wn * kCfgs[cfg].tn * 16;
+    if (G != tiles_of_cfg(cfg, M, N)) {
+        const size_t slot = (size_t)BM * BN * sizeof(float);
+        if (tiles_of_cfg(cfg, M, N) > (long)kGemmMaxTickets || slot * 2 > slab_cap_bytes) G = tiles_of_cfg(cfg, M, N);
+        else if ((size_t)G * 2 * slot > slab_cap_bytes) G = (long)(slab_cap_bytes / (2 * slot));
     }
     *cfg_out = cfg;
-    *split_out = S;
+    *G_out = (unsigned)G;
 }
 
 // ---------------------------------------------------------------------------
@@ -678,6 +540,8 @@ extern "C" int paella_prof_collect(double* total_ms, double* total_flops, double
     return PAELLA_OK;
 }
 
+// `ws` = a split-K region: kGemmTicketBytes of tickets (zero when first handed over, see paella_workspace_init) followed
+// by slab space.  cfg < 0: heuristic.  splitk > 0: G = tiles * splitk (classic split-K); splitk < 0: G = -splitk workgroups.
 static int launch_gemm_cfg_impl(const GemmArgs& g, int cfg, int splitk, void* ws, size_t ws_bytes, hipStream_t st) {
     if (g.M <= 0 || g.N <= 0) return PAELLA_OK;
     if ((g.K & 3) || (g.N & 3) || (g.lda & 3) || (g.ldw & 3) || (g.ldc & 3 && g.ep.store_mode != STORE_PIXSHUF_NCHW)) {
@@ -698,84 +562,76 @@ static int launch_gemm_cfg_impl(const GemmArgs& g, int cfg, int splitk, void* ws
         const int rc = launch_gemm_bf16(g, -1, 1, ws, ws_bytes, st);
         if (rc != PAELLA_ERR_STATE) return rc;
     }
-    int S = splitk;
-    if (cfg < 0) choose_config(g.M, g.N, g.K, ws ? ws_bytes : 0, &cfg, &S);
-    if (cfg >= 16 && cfg < 25) return launch_gemm_ws(g, (cfg - 16) / 3, (cfg - 16) % 3, S, ws, ws_bytes, st);
-    if (cfg >= 64) {  // ablation builds (tools only): cfg = 64 + 16*ABL + tile (tile in {2,5}); results are NOT a GEMM
-        const int abl = (cfg - 64) / 16, tile = (cfg - 64) % 16;
-        int kslice = ((g.K + (S < 1 ? 1 : S) - 1) / (S < 1 ? 1 : S) + 31) / 32 * 32;
-        const int Sx = (g.K + kslice - 1) / kslice;
-#define ABL_LAUNCH(WMv, WNv, TMv, TNv, A)                                                                                     \
-    do {                                                                                                                       \
-        constexpr int BM = WMv * TMv * 16, BN = WNv * TNv * 16;                                                                \
-        const int tm_ = (g.M + BM - 1) / BM, tn_ = (g.N + BN - 1) / BN;                                                        \
-        hipLaunchKernelGGL((gemm_nt_kernel<WMv, WNv, TMv, TNv, 2, 0, false, A>), dim3(tm_ * tn_, Sx), dim3(256), 0, st, g, \
-                           kslice, Sx, reinterpret_cast<float*>(ws), tm_, tn_, (unsigned*)nullptr, 0u);                        \
-    } while (0)
-        if (abl == 4) {  // timeline probe: the real kernel (in-launch combine) with time stamps
-            unsigned* ctr = nullptr;
-            if (Sx > 1) RET_IF_G(gemm_tile_counters(&ctr, st));
-#define TL_LAUNCH(WMv, WNv, TMv, TNv)                                                                                          \
-    do {                                                                                                                       \
-        constexpr int BM = WMv * TMv * 16, BN = WNv * TNv * 16;                                                                \
-        const int tm_ = (g.M + BM - 1) / BM, tn_ = (g.N + BN - 1) / BN;                                                        \
-        hipLaunchKernelGGL((gemm_nt_kernel<WMv, WNv, TMv, TNv, 2, 0, false, 4>), dim3(tm_ * tn_, Sx), dim3(256), 0, st, g,     \
-                           kslice, Sx, reinterpret_cast<float*>(ws), tm_, tn_, ctr, (unsigned)((size_t)tm_ * tn_ * Sx * BM * BN * 4)); \
-    } while (0)
-            if (tile == 5) TL_LAUNCH(2, 2, 1, 1); else TL_LAUNCH(2, 2, 2, 2);
-#undef TL_LAUNCH
-            LAUNCH_CHECK_RET();
-            return PAELLA_OK;
-        }
-        if (tile == 5) { if (abl == 1) ABL_LAUNCH(2, 2, 1, 1, 1); else if (abl == 2) ABL_LAUNCH(2, 2, 1, 1, 2); else ABL_LAUNCH(2, 2, 1, 1, 3); }
-        else { if (abl == 1) ABL_LAUNCH(2, 2, 2, 2, 1); else if (abl == 2) ABL_LAUNCH(2, 2, 2, 2, 2); else ABL_LAUNCH(2, 2, 2, 2, 3); }
-#undef ABL_LAUNCH
-        LAUNCH_CHECK_RET();
-        return PAELLA_OK;
+    const bool have_ws = ws && ws_bytes > kGemmTicketBytes;
+    const size_t slab_cap = have_ws ? ws_bytes - kGemmTicketBytes : 0;
+    unsigned G = 0;
+    if (cfg < 0) {
+        choose_config(g.M, g.N, g.K, slab_cap, &cfg, &G);
+    } else {
+        if (cfg >= kNumCfgs) { paella_set_error("gemm: bad tile config %d", cfg); return PAELLA_ERR_ARG; }
+        const long T = tiles_of_cfg(cfg, g.M, g.N);
+        G = splitk < 0 ? (unsigned)(-splitk) : (unsigned)(T * (splitk < 1 ? 1 : splitk));
     }
-    const bool pd1 = cfg >= 32;
-    if (pd1) cfg -= 32;
-    if (cfg >= kNumCfgs) { paella_set_error("gemm: bad tile config %d", cfg); return PAELLA_ERR_ARG; }
-    if (S < 1) S = 1;
-    int kslice = ((g.K + S - 1) / S + 31) / 32 * 32;
-    S = (g.K + kslice - 1) / kslice;
-    if (S < 1) S = 1;
-    if (S > 1) {
-        const int BM = kCfgs[cfg].wm * kCfgs[cfg].tm * 16, BN = kCfgs[cfg].wn * kCfgs[cfg].tn * 16;
-        const size_t tiles = (size_t)((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
-        if (!ws || tiles * S * BM * BN * sizeof(float) > ws_bytes || tiles > (size_t)kMaxTiles) {
-            paella_set_error("gemm: split-K workspace too small");
+    const TileCfg& tc = kCfgs[cfg];
+    const int BM = tc.wm * tc.tm * 16, BN = tc.wn * tc.tn * 16;
+    SkPlan p;
+    p.tiles_m = (g.M + BM - 1) / BM;
+    p.tiles_n = (g.N + BN - 1) / BN;
+    p.KT = (g.K + 31) / 32;
+    const unsigned long long T = (unsigned long long)p.tiles_m * p.tiles_n;
+    const unsigned long long U = T * (unsigned long long)p.KT;
+    if (U >= (1ull << 31)) { paella_set_error("gemm: problem too large (%llu work units)", U); return PAELLA_ERR_ARG; }
+    p.U = (unsigned)U;
+    if (G < 1) G = 1;
+    if (G > p.U) G = p.U;
+    if (g.ln_stats && p.tiles_m > 1) {
+        // the LayerNorm-on-load variant computes its row statistics once per workgroup: keep every range inside one tile
+        unsigned S = G / (unsigned)T;
+        if (S < 1) S = 1;
+        while (p.KT % (int)S) --S;
+        G = (unsigned)T * S;
+    }
+    unsigned slab_bytes = 0;
+    if (G != (unsigned)T) {  // ranges are not tile-aligned: partial tiles go through slabs + tickets
+        const unsigned long long need = 2ull * G * BM * BN * sizeof(float);
+        if (!have_ws || need > slab_cap || need >= (1ull << 31) || T > kGemmMaxTickets) {
+            paella_set_error("gemm: split-K workspace too small (%llu slab bytes for %u workgroups, %llu tiles)", need, G, T);
             return PAELLA_ERR_WORKSPACE;
         }
+        slab_bytes = (unsigned)need;
     }
-    float* slabs = reinterpret_cast<float*>(ws);
-    // prefetch depth per tile config: as deep as ~32-48 staging VGPRs allow
-    if (!pd1) {
-        switch (cfg) {
-            case 0: launch_one<2, 2, 4, 4, 1>(g, kslice, S, slabs, st); break;
-            case 1: launch_one<2, 2, 4, 2, 2>(g, kslice, S, slabs, st); break;
-            case 2: launch_one<2, 2, 2, 2, 2>(g, kslice, S, slabs, st); break;
-            case 3: launch_one<2, 2, 2, 1, 2>(g, kslice, S, slabs, st); break;
-            case 4: launch_one<2, 2, 1, 2, 2>(g, kslice, S, slabs, st); break;
-            case 5: launch_one<2, 2, 1, 1, 2>(g, kslice, S, slabs, st); break;
-            case 6: launch_one<1, 4, 1, 1, 2>(g, kslice, S, slabs, st); break;
-            case 7: launch_one<1, 4, 1, 2, 2>(g, kslice, S, slabs, st); break;
-            case 8: launch_one<1, 4, 2, 2, 2>(g, kslice, S, slabs, st); break;
-            case 9: launch_one<2, 4, 4, 2, 2>(g, kslice, S, slabs, st); break;
-            case 10: launch_one<4, 2, 2, 4, 2>(g, kslice, S, slabs, st); break;
-            case 13: launch_one<2, 4, 4, 2, 1>(g, kslice, S, slabs, st); break;  // as 9 / 10 with all fragment reads up front (1-deep global prefetch)
-            case 14: launch_one<4, 2, 2, 4, 1>(g, kslice, S, slabs, st); break;
-            case 11: launch_one<2, 4, 2, 2, 2>(g, kslice, S, slabs, st); break;
-            case 12: launch_one<4, 2, 2, 2, 2>(g, kslice, S, slabs, st); break;
-        }
-    } else {  // 1-deep prefetch variants kept for A/B measurements (tools/gemm_tune.py, cfg + 32)
-        switch (cfg) {
-            case 2: launch_one<2, 2, 2, 2, 1>(g, kslice, S, slabs, st); break;
-            case 4: launch_one<2, 2, 1, 2, 1>(g, kslice, S, slabs, st); break;
-            case 5: launch_one<2, 2, 1, 1, 1>(g, kslice, S, slabs, st); break;
-            default: paella_set_error("gemm: no PD=1 variant for tile config %d", cfg); return PAELLA_ERR_ARG;
-        }
+    unsigned* tickets = have_ws ? reinterpret_cast<unsigned*>(ws) : nullptr;
+    float* slabs = have_ws ? reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + kGemmTicketBytes) : nullptr;
+#define GEMM_CASE(id, WMv, WNv, TMv, TNv, PDv) \
+    case id: launch_one<WMv, WNv, TMv, TNv, PDv>(g, p, G, slabs, tickets, slab_bytes, st); break;
+    switch (cfg) {
+        GEMM_CASE(0, 2, 2, 4, 4, 1)
+        GEMM_CASE(1, 2, 2, 4, 2, 2)
+        GEMM_CASE(2, 2, 2, 2, 2, 2)
+        GEMM_CASE(3, 2, 2, 2, 1, 2)
+        GEMM_CASE(4, 2, 2, 1, 2, 2)
+        GEMM_CASE(5, 2, 2, 1, 1, 2)
+        GEMM_CASE(6, 1, 4, 1, 1, 2)
+        GEMM_CASE(7, 1, 4, 1, 2, 2)
+        GEMM_CASE(8, 1, 4, 2, 2, 2)
+        GEMM_CASE(9, 4, 2, 2, 4, 1)
+        GEMM_CASE(10, 2, 4, 4, 2, 1)
+        GEMM_CASE(11, 4, 1, 2, 2, 2)
+        GEMM_CASE(12, 4, 1, 2, 4, 2)
+        GEMM_CASE(13, 4, 1, 1, 4, 2)
+        GEMM_CASE(14, 4, 2, 2, 2, 2)
+        GEMM_CASE(15, 8, 1, 2, 2, 2)
+        GEMM_CASE(16, 8, 1, 2, 4, 1)
+        GEMM_CASE(17, 8, 1, 1, 4, 2)
+        GEMM_CASE(18, 2, 2, 2, 2, 1)
+        GEMM_CASE(19, 2, 2, 1, 1, 1)
+        GEMM_CASE(20, 4, 1, 2, 4, 1)
+        GEMM_CASE(21, 4, 1, 1, 2, 2)
+        GEMM_CASE(22, 2, 2, 1, 4, 2)
+        GEMM_CASE(23, 1, 4, 2, 1, 2)
+        default: paella_set_error("gemm: bad tile config %d", cfg); return PAELLA_ERR_ARG;
     }
+#undef GEMM_CASE
     LAUNCH_CHECK_RET();
     return PAELLA_OK;
 }
@@ -783,3 +639,12 @@ static int launch_gemm_cfg_impl(const GemmArgs& g, int cfg, int splitk, void* ws
 int launch_gemm(const GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t st) {
     return launch_gemm_cfg(g, -1, 1, ws, ws_bytes, st);
 }
+
+// Zero the ticket header of a freshly allocated workspace (every workspace handed to a paella_* entry point starts with
+// it; the kernels leave it zero).  Stream-ordered, no host synchronisation.
+extern "C" int paella_workspace_init(void* ws, size_t ws_bytes, void* stream) {
+    if (!ws || ws_bytes < kGemmTicketBytes) { paella_set_error("workspace smaller than its %zu-byte header", (size_t)kGemmTicketBytes); return PAELLA_ERR_WORKSPACE; }
+    HIP_CHECK_RET(hipMemsetAsync(ws, 0, kGemmTicketBytes, (hipStream_t)stream));
+    return PAELLA_OK;
+}
+extern "C" size_t paella_workspace_header_bytes(void) { return kGemmTicketBytes; }

@@ -304,17 +304,13 @@ static const unsigned short* shadow_lookup(const float* W) {
 // ---------------------------------------------------------------------------
 // launcher
 // ---------------------------------------------------------------------------
-int gemm_tile_counters(unsigned** out, hipStream_t st);  // gemm.hip
-int gemm_max_tiles();
-
 template <int WM, int WN, int TM, int TN>
-static void launch_b(const GemmArgs& g, const unsigned short* Wb, int kslice, int S, float* slabs, hipStream_t st) {
+static void launch_b(const GemmArgs& g, const unsigned short* Wb, int kslice, int S, float* slabs, unsigned* tickets, hipStream_t st) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
     const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
     dim3 grid(tiles_m * tiles_n, S);
-    unsigned* counters = nullptr;
+    unsigned* counters = S > 1 ? tickets : nullptr;
     const size_t slab_bytes = (size_t)tiles_m * tiles_n * S * BM * BN * sizeof(float);
-    if (S > 1) (void)gemm_tile_counters(&counters, st);
     if (g.a_scale)
         hipLaunchKernelGGL((gemm_bf16_kernel<WM, WN, TM, TN, 1>), grid, dim3(256), 0, st, g, Wb, kslice, S, slabs, tiles_m, tiles_n, counters, (unsigned)slab_bytes);
     else if (g.ln_stats)
@@ -345,17 +341,21 @@ int launch_gemm_bf16(const GemmArgs& g, int tile, int splitk, void* ws, size_t w
     const int bsz = tile == 0 ? 128 : (tile == 1 ? 64 : 32);
     int kslice = ((g.K + S - 1) / S + 63) / 64 * 64;
     S = (g.K + kslice - 1) / kslice;
-    while (S > 1 && (!ws || (size_t)S * tiles_of(bsz) * bsz * bsz * sizeof(float) > ws_bytes || tiles_of(bsz) > gemm_max_tiles() ||
+    // ws = ticket header (kGemmTicketBytes, see common.h) + slab space
+    const bool have_ws = ws && ws_bytes > kGemmTicketBytes;
+    const size_t slab_cap = have_ws ? ws_bytes - kGemmTicketBytes : 0;
+    while (S > 1 && (!have_ws || (size_t)S * tiles_of(bsz) * bsz * bsz * sizeof(float) > slab_cap || tiles_of(bsz) > (long)kGemmMaxTickets ||
                      (size_t)S * tiles_of(bsz) * bsz * bsz * sizeof(float) >= ((size_t)1 << 31))) {
         S /= 2;
         kslice = ((g.K + S - 1) / S + 63) / 64 * 64;
         S = (g.K + kslice - 1) / kslice;
     }
-    float* slabs = reinterpret_cast<float*>(ws);
+    unsigned* tickets = have_ws ? reinterpret_cast<unsigned*>(ws) : nullptr;
+    float* slabs = have_ws ? reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + kGemmTicketBytes) : nullptr;
     switch (tile) {
-        case 0: launch_b<2, 2, 4, 4>(g, Wb, kslice, S, slabs, st); break;
-        case 1: launch_b<2, 2, 2, 2>(g, Wb, kslice, S, slabs, st); break;
-        default: launch_b<2, 2, 1, 1>(g, Wb, kslice, S, slabs, st); break;
+        case 0: launch_b<2, 2, 4, 4>(g, Wb, kslice, S, slabs, tickets, st); break;
+        case 1: launch_b<2, 2, 2, 2>(g, Wb, kslice, S, slabs, tickets, st); break;
+        default: launch_b<2, 2, 1, 1>(g, Wb, kslice, S, slabs, tickets, st); break;
     }
     LAUNCH_CHECK_RET();
     return PAELLA_OK;

@@ -32,7 +32,7 @@ struct Arena {
     }
 };
 
-static const size_t kSplitKBudget = (size_t)96 << 20;  // bytes of split-K slab space in every workspace
+static const size_t kSplitKBudget = (size_t)96 << 20;  // bytes of the split-K region (ticket header + slabs) at the START of every workspace
 
 enum Repack {
     RP_COPY,      // as is

@@ -365,11 +365,8 @@ extern "C" int paella_unet_set_timestep_freqs(paella_unet* m, const float* host_
     return PAELLA_OK;
 }
 
-int gemm_tile_counters(unsigned** out, hipStream_t st);  // gemm.hip
-
 extern "C" int paella_unet_finalize(paella_unet* m, void* stream) {
     if (!m) { paella_set_error("null argument"); return PAELLA_ERR_ARG; }
-    { unsigned* ctr = nullptr; RET_IF(gemm_tile_counters(&ctr, (hipStream_t)stream)); }  // allocate the split-K tickets now: a first forward may run under stream capture
     for (auto& kv : m->t)  // bf16 shadow copies for the opt-in fast mode are (re)made from the tensors as loaded now
         if (kv.second.p && kv.second.n >= 4096) RET_IF(gemm_register_weight(kv.second.p, kv.second.n, (hipStream_t)stream));
     for (auto& kv : m->specs) {
@@ -418,6 +415,7 @@ static int64_t level_rows(const paella_unet* m, int B, int H, int W, int l) {
 static void carve_forward(const paella_unet* m, Arena& a, int B, int H, int W, int S, FwdBuffers& f) {
     const paella_unet_config& c = m->cfg;
     const int p2 = c.patch_size * c.patch_size;
+    f.splitk = a.take(kSplitKBudget / sizeof(float));  // FIRST: its ticket header sits at a fixed offset (paella_workspace_init)
     size_t hmax = (size_t)B * H * W * c.c_out;
     size_t gmax = (size_t)B * H * W * c.c_out;
     const size_t emb = (size_t)level_rows(m, B, H, W, 0) * c.c_in * p2;
@@ -439,15 +437,14 @@ static void carve_forward(const paella_unet* m, Arena& a, int B, int H, int W, i
     f.ts = a.take((size_t)B * (m->ts_total > 0 ? m->ts_total : 1));
     f.remb = a.take((size_t)B * c.c_r);
     f.rowstat = a.take(hmax / 8 + 64);  // [rows, C/16, 2]
-    f.splitk = a.take(kSplitKBudget / sizeof(float));
     (void)S;
 }
 
 static void carve_cond(const paella_unet* m, Arena& a, int B, int S, FwdBuffers& f) {
+    f.splitk = a.take(kSplitKBudget / sizeof(float));  // FIRST, as in carve_forward
     f.c_embed = a.take((size_t)B * S * m->cfg.c_cond);
     f.c_silu = a.take((size_t)B * S * m->cfg.c_cond);
     f.kvm = a.take((size_t)B * S * m->c_max);
-    f.splitk = a.take(kSplitKBudget / sizeof(float));
 }
 
 extern "C" size_t paella_unet_workspace_bytes(const paella_unet* m, int B, int H, int W, int S) {
@@ -828,7 +825,7 @@ extern "C" int paella_op_gemm(const float* A, const float* W, const float* bias,
     g.ep.bias = bias; g.ep.act = act; g.ep.residual = residual; g.ep.ldr = N;
     return launch_gemm_cfg(g, tile_cfg, splitk, ws, ws_bytes, (hipStream_t)stream);
 }
-extern "C" int paella_debug_register_weight(const float* w, size_t numel, int on) {
+extern "C" int paella_test_register_weight(const float* w, size_t numel, int on) {
     if (on) return gemm_register_weight(w, numel, 0);
     gemm_unregister_weight(w);
     return PAELLA_OK;

@@ -192,7 +192,7 @@ __global__ void chain_kernel(float* p, int bytes4) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < bytes4) p[i] += 1.0f;
 }
-extern "C" int paella_debug_launch_chain(float* buf, int n_elems, int blocks, int n_launches, void* stream) {
+extern "C" int paella_test_launch_chain(float* buf, int n_elems, int blocks, int n_launches, void* stream) {
     for (int i = 0; i < n_launches; ++i) hipLaunchKernelGGL(chain_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, buf, n_elems);
     LAUNCH_CHECK_RET();
     return PAELLA_OK;

@@ -156,11 +156,9 @@ extern "C" int paella_vqgan_load_tensor(paella_vqgan* v, const char* key, const 
     return repack_into(sp.kind, dev_src, sp.shape, v->t[key], (hipStream_t)stream);
 }
 
-int gemm_tile_counters(unsigned** out, hipStream_t st);  // gemm.hip
 
 extern "C" int paella_vqgan_finalize(paella_vqgan* v, void* stream) {
     if (!v) { paella_set_error("null argument"); return PAELLA_ERR_ARG; }
-    { unsigned* ctr = nullptr; RET_IF(gemm_tile_counters(&ctr, (hipStream_t)stream)); }  // split-K tickets must exist before any captured launch
     hipStream_t st = (hipStream_t)stream;
     for (auto& kv : v->specs) {
         auto it = v->t.find(kv.first);
@@ -217,6 +215,7 @@ struct VqBuffers { float *x, *t, *g, *a, *lat, *qe, *splitk; };
 
 // largest activation: at the image-side level the grid is (h*2^(L-1)) x (w*2^(L-1)) with c_levels[0] channels
 static void vq_carve(const paella_vqgan* v, Arena& a, int B, int h, int w, VqBuffers& f) {
+    f.splitk = a.take(kSplitKBudget / sizeof(float));  // FIRST: its ticket header sits at a fixed offset (paella_workspace_init)
     const int L = v->cfg.levels;
     size_t xmax = 0, amax = 0;
     for (int i = 0; i < L; ++i) {
@@ -239,7 +238,6 @@ static void vq_carve(const paella_vqgan* v, Arena& a, int B, int h, int w, VqBuf
     f.a = a.take(amax ? amax : 4);
     f.lat = a.take((size_t)B * h * w * v->cfg.c_latent);
     f.qe = a.take((size_t)B * h * w * v->cfg.c_latent);
-    f.splitk = a.take(kSplitKBudget / sizeof(float));
 }
 
 extern "C" size_t paella_vqgan_workspace_bytes(const paella_vqgan* v, int B, int h, int w) {

@@ -155,7 +155,7 @@ class VQModel(nn.Module):
         dev = self._device()
         if self._ws is None or self._ws.numel() < nbytes or self._ws.device != dev:
             self._ws = None
-            self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+            self._ws = _lib.new_workspace(nbytes, dev)
         return self._ws
 
     def _quantize_rows(self, flat):

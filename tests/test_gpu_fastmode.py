@@ -8,6 +8,7 @@ import pytest
 import torch
 
 import paella_amd
+from paella_amd import _lib
 from oracle import golden_configs as G
 from tests.helpers import cond_for, to_dev, weights_for
 
@@ -41,15 +42,15 @@ def test_bf16_gemm_is_exact_on_rounded_operands(built_lib, tile, splitk, M, N, K
     ref = (A.bfloat16().double() @ W.bfloat16().double().t() + bias.double()).float()
     Ad, Wd, bd = A.to(DEV), W.to(DEV), bias.to(DEV)
     C = torch.full((M, N), float("nan"), device=DEV)
-    ws = torch.empty(64 << 20, dtype=torch.uint8, device=DEV)
-    assert lib.paella_debug_register_weight(_p(Wd), Wd.numel(), 1) == 0
+    ws = _lib.new_workspace(64 << 20, DEV)
+    assert lib.paella_test_register_weight(_p(Wd), Wd.numel(), 1) == 0
     try:
         paella_amd.set_gemm_precision("bf16")   # converts the registered matrix
         rc = lib.paella_op_gemm(_p(Ad), _p(Wd), _p(bd), None, _p(C), M, N, K, 0, tile, splitk, _p(ws), ws.numel(), _st())
         assert rc == 0, lib.paella_last_error()
         torch.cuda.synchronize()
     finally:
-        lib.paella_debug_register_weight(_p(Wd), Wd.numel(), 0)
+        lib.paella_test_register_weight(_p(Wd), Wd.numel(), 0)
     np.testing.assert_allclose(C.cpu().numpy(), ref.numpy(), atol=2e-3, rtol=2e-5)
 
 

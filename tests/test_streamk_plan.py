@@ -1,0 +1,94 @@
+"""CPU: the stream-K work decomposition of paella_amd/csrc/gemm.hip, restated in Python and checked exhaustively on small cases.
+
+The kernel gives workgroup g of G the unit range [g*U/G, (g+1)*U/G) of the U = tiles*KT (tile, K-step) units.  Partial tiles are
+published to slab slot 2g ("head": the segment starts the workgroup's range) or 2g+1 (a later, necessarily last, segment) and the
+last arriver recomputes from (tile, G, U) alone which workgroups contributed and in which slot.  This test proves, for every
+(tiles, KT, G) in a grid, that reader and writers agree: same part set, same slots, ticket target = parts - 1, every K step of
+every tile covered exactly once.  (No GPU: pure integer logic mirrored from the kernel source.)"""
+import itertools
+
+import pytest
+
+
+def start(g, U, G):
+    return (g * U) // G
+
+
+def writer_segments(g, U, G, KT):
+    """What workgroup g does: list of (tile, k0, k1, first_segment)."""
+    u0, u1 = start(g, U, G), start(g + 1, U, G)
+    segs, first = [], True
+    tile, kt, i, n = u0 // KT, u0 % KT, 0, u1 - u0
+    while i < n:
+        seg = min(KT - kt, n - i)
+        segs.append((tile, kt, kt + seg, first))
+        first = False
+        i += seg
+        kt += seg
+        if kt == KT:
+            kt = 0
+            tile += 1
+    return segs
+
+
+def reader_parts(tile, U, G, KT):
+    """What the last arriver of `tile` computes: [(workgroup, slot)] in summation order."""
+    tb = tile * KT
+    g_first = ((tb + 1) * G - 1) // U
+    g_last = ((tb + KT) * G - 1) // U
+    parts = []
+    for gp in range(g_first, g_last + 1):
+        tail = gp == g_first and start(g_first, U, G) < tb
+        parts.append((gp, 2 * gp + (1 if tail else 0)))
+    return parts
+
+
+@pytest.mark.parametrize("tiles,KT", [(1, 1), (1, 7), (3, 5), (7, 4), (10, 40), (80, 40), (5, 13), (2, 160)])
+def test_reader_and_writers_agree(tiles, KT):
+    U = tiles * KT
+    for G in sorted(set(list(range(1, min(U, 70) + 1)) + [U, max(1, U // 2), max(1, U - 1), min(U, 256), min(U, 512)])):
+        if G > U:
+            continue
+        cover = {t: [0] * KT for t in range(tiles)}
+        published = {}  # slot -> (tile, k0, k1)
+        full = set()
+        for g in range(G):
+            segs = writer_segments(g, U, G, KT)
+            assert segs, "every workgroup owns at least one unit when G <= U"
+            for (tile, k0, k1, first) in segs:
+                for k in range(k0, k1):
+                    cover[tile][k] += 1
+                if k0 == 0 and k1 == KT:
+                    full.add(tile)
+                else:
+                    slot = 2 * g + (0 if first else 1)
+                    assert slot not in published, "a slab slot is written twice in one launch"
+                    published[slot] = (tile, k0, k1)
+        assert all(all(c == 1 for c in v) for v in cover.values()), (tiles, KT, G)
+        for tile in range(tiles):
+            parts = reader_parts(tile, U, G, KT)
+            if tile in full:
+                assert len(parts) == 1  # no ticket is ever taken for this tile
+                continue
+            ks = []
+            for (gp, slot) in parts:
+                assert slot in published and published[slot][0] == tile, (tiles, KT, G, tile, parts)
+                ks.append(published[slot][1:])
+            # the parts tile the K range in ascending order: fixed, launch-independent summation order
+            assert ks[0][0] == 0 and ks[-1][1] == KT and all(a[1] == b[0] for a, b in zip(ks, ks[1:]))
+            n_writers = sum(1 for v in published.values() if v[0] == tile)
+            assert n_writers == len(parts)  # ticket target = parts - 1 arrivals before the last
+
+
+def test_classic_cases_are_special_cases():
+    # G == tiles: one whole tile per workgroup, nothing published
+    for tiles, KT in [(12, 8), (1000, 20)]:
+        U = tiles * KT
+        for g in range(tiles):
+            assert writer_segments(g, U, tiles, KT) == [(g, 0, KT, True)]
+    # G == tiles * S with S | KT: classic split-K, S equal slices per tile
+    tiles, KT, S = 6, 40, 4
+    U, G = tiles * KT, tiles * S
+    for g in range(G):
+        (tile, k0, k1, first), = writer_segments(g, U, G, KT)
+        assert tile == g // S and k0 == (g % S) * (KT // S) and k1 == k0 + KT // S and first

@@ -14,7 +14,7 @@ lib = _lib.load()
 A = torch.randn(M, K, device="cuda")
 W = torch.randn(N, K, device="cuda")
 C = torch.empty(M, N, device="cuda")
-ws = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+ws = _lib.new_workspace(256 << 20, "cuda")
 flush = torch.empty(512 << 20, dtype=torch.uint8, device="cuda")
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 for _ in range(iters):

@@ -47,13 +47,11 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--big-only", action="store_true", help="only the large-tile candidates without split-K")
-    ap.add_argument("--debug-switches", type=int, default=0, help="paella_debug_set_spread bits (2 = direct global->LDS staging)")
     ap.add_argument("--only", default=None, help="substring filter on the shape name")
     a = ap.parse_args()
     lib = _lib.load()
-    lib.paella_debug_set_spread(a.debug_switches)
     st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    ws = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+    ws = _lib.new_workspace(256 << 20, "cuda")
     results = {}
     for name, (M, N, K) in SHAPES.items():
         if a.only and a.only not in name:
@@ -66,14 +64,30 @@ def main():
         Ws = [torch.randn(N, K, device="cuda") for _ in range(ncopy)]
         C = torch.empty(M, N, device="cuda")
         row = {}
-        variants = [(-1, 1)] + [(c, s) for c in range(9) for s in (1, 2, 4, 8, 16)] + [(c, s) for c in (34, 36, 37) for s in (1, 2, 4, 8, 16)]
+        # (tile config, splitk): splitk > 0 = tiles * splitk workgroups (classic split-K), splitk < 0 = exactly -splitk
+        # workgroups walking balanced contiguous (tile, K-step) ranges
+        tile_of = {0: (128, 128), 1: (128, 64), 2: (64, 64), 3: (64, 32), 4: (32, 64), 5: (32, 32), 6: (16, 64), 7: (16, 128), 8: (32, 128),
+                   9: (128, 128), 10: (128, 128), 11: (128, 32), 12: (128, 64), 13: (64, 64), 14: (128, 64), 15: (256, 32), 16: (256, 64),
+                   17: (128, 64), 18: (64, 64), 19: (32, 32), 20: (128, 64), 21: (64, 32), 22: (32, 128), 23: (32, 64)}
+        def fits(c):  # skip tiles that waste more than half their rows on this M
+            bm = tile_of[c][0]
+            return bm <= 2 * max(M, 16) or c in (2, 5)
+        cands = [c for c in tile_of if fits(c)]
+        variants = [(-1, 1)] + [(c, s) for c in cands for s in (1, 2, 3, 4, 6, 8, 12, 16)] + \
+                   [(c, -G) for c in cands for G in (256, 384, 512, 640, 768, 1024, 1280, 1536, 2048)]
         if a.big_only:
-            variants = [(-1, 1)] + [(c, 1) for c in (0, 1, 2, 9, 10, 11, 12, 13, 14, 34)]
+            variants = [(-1, 1)] + [(c, 1) for c in (0, 1, 2, 9, 10, 12, 14, 16, 18)]
         if M >= 4096:  # MFMA-bound: no split-K, few candidates, few iterations
-            variants = [(-1, 1)] + [(c, 1) for c in (0, 1, 2, 9, 10, 11, 12, 13, 14, 34)]
+            variants = [(-1, 1)] + [(c, 1) for c in (0, 1, 2, 9, 10, 12, 14, 16, 18)]
         for cfg, sk in variants:
-            if sk > 1 and (K // sk < 128 or sk * max(M, 128) * N * 4 > ws.numel()):
+            if sk > 1 and K // sk < 96:
                 continue
+            if sk < 0:
+                bm, bn = tile_of[cfg]
+                T = -(-M // bm) * -(-N // bn)
+                U = T * -(-K // 32)
+                if -sk > U or U / -sk < 2.5 or -sk < T // 2:   # too few units per workgroup / more than 2 tiles per workgroup
+                    continue
             def run(W):
                 return lib.paella_op_gemm(A.data_ptr(), W.data_ptr(), None, None, C.data_ptr(), M, N, K, 0, cfg, sk, ws.data_ptr(), ws.numel(), st())
             if run(Ws[0]) != 0:
@@ -92,15 +106,16 @@ def main():
             row["%d/%d" % (cfg, sk)] = round(us, 2)
         flops = 2.0 * M * N * K
         best = min((v, k) for k, v in row.items() if not k.startswith("-1"))
-        pd1 = min([(v, k) for k, v in row.items() if int(k.split('/')[0]) >= 32] or [(0, '-')])
+        top = sorted((v, k) for k, v in row.items() if not k.startswith("-1"))[:6]
         heur = row.get("-1/1")
         results[name] = {"MNK": [M, N, K], "us": row, "best": best[1], "best_us": best[0], "best_tflops": round(flops / best[0] / 1e6, 1),
                          "heuristic_us": heur, "heuristic_tflops": round(flops / heur / 1e6, 1) if heur else None,
                          "hbm_floor_us": round((M * K + N * K + M * N) * 4 / 6.3e6, 2), "mfma_floor_us": round(flops / 157.3e6, 2)}
         r = results[name]
         print("%-34s all %s" % (name, " ".join("%s=%.0f" % kv for kv in row.items())) if (M >= 4096 or a.big_only) else "", end="\n" if (M >= 4096 or a.big_only) else "")
-        print("%-28s best %-6s %8.1f us %6.1f TF | heuristic %8.1f us %6.1f TF | best PD=1 %-6s %6.1f us | floors hbm %.1f mfma %.1f us" %
-              (name, r["best"], r["best_us"], r["best_tflops"], heur, r["heuristic_tflops"], pd1[1], pd1[0], r["hbm_floor_us"], r["mfma_floor_us"]), flush=True)
+        print("%-28s best %-8s %8.1f us %6.1f TF | heuristic %8.1f us %6.1f TF | floors hbm %.1f mfma %.1f us | top: %s" %
+              (name, r["best"], r["best_us"], r["best_tflops"], heur, r["heuristic_tflops"], r["hbm_floor_us"], r["mfma_floor_us"],
+               " ".join("%s=%.1f" % (k, v) for v, k in top)), flush=True)
     if a.out:
         os.makedirs(os.path.dirname(a.out), exist_ok=True)
         json.dump(results, open(a.out, "w"), indent=1)

@@ -8,12 +8,12 @@ buf = torch.zeros(1 << 20, device="cuda")
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 for blocks, n_el in ((1, 256), (256, 65536), (1024, 262144)):
     for n in (200, 2000):
-        lib.paella_debug_launch_chain(buf.data_ptr(), n_el, blocks, 50, st)
+        lib.paella_test_launch_chain(buf.data_ptr(), n_el, blocks, 50, st)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         e0.record()
-        lib.paella_debug_launch_chain(buf.data_ptr(), n_el, blocks, n, st)
+        lib.paella_test_launch_chain(buf.data_ptr(), n_el, blocks, n, st)
         e1.record()
         th = time.perf_counter() - t0
         torch.cuda.synchronize()
@@ -23,10 +23,10 @@ for blocks, n_el in ((1, 256), (256, 65536), (1024, 262144)):
     with torch.cuda.stream(s):
         g = torch.cuda.CUDAGraph()
         sp = ctypes.c_void_p(s.cuda_stream)
-        lib.paella_debug_launch_chain(buf.data_ptr(), n_el, blocks, 10, sp)
+        lib.paella_test_launch_chain(buf.data_ptr(), n_el, blocks, 10, sp)
         torch.cuda.synchronize()
         with torch.cuda.graph(g, stream=s):
-            lib.paella_debug_launch_chain(buf.data_ptr(), n_el, blocks, 500, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+            lib.paella_test_launch_chain(buf.data_ptr(), n_el, blocks, 500, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
     g.replay(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

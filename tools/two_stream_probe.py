@@ -4,8 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from paella_amd import _lib
 lib = _lib.load()
-ws1 = torch.empty(128 << 20, dtype=torch.uint8, device="cuda")
-ws2 = torch.empty(128 << 20, dtype=torch.uint8, device="cuda")
+ws1 = _lib.new_workspace(128 << 20, "cuda")
+ws2 = _lib.new_workspace(128 << 20, "cuda")
 def chain(M, N, K, Ws, ws, stream):
     A = chain.A[(M, K)]; C = chain.C[(M, N)]
     sp = ctypes.c_void_p(stream.cuda_stream)
