@@ -1,7 +1,10 @@
 #!/usr/bin/env python
 """Headline benchmark: images/sec + single-image ms for Paella sampling, 256x256 px (32x32 tokens) @ 8 steps.
 
-Contract (driver):  python bench.py --gpus N --steps K --warmup W      (N>1: launched by torch.distributed.run)
+Contract (driver):  python bench.py --gpus N --steps K --warmup W
+    N = 1 runs in-process.  N > 1 needs one process per GPU: under torch.distributed.run (RANK / WORLD_SIZE set) this file is
+    a rank; started plainly with --gpus N > 1 it re-launches ITSELF under `python -m torch.distributed.run --nproc-per-node N`
+    on 127.0.0.1 and relays the ranks' output.
 One "step" = one pass of the hot path over one batch of synthetic input:
     sample() -- 8 denoising steps, classifier-free guidance 8.0 (cond + uncond rows batched per evaluation),
     temperature 1.0 -> 0.2, renoise 7 -- followed by VQGAN f8 decode_indices to 256x256 px.
@@ -11,21 +14,23 @@ seeded synthetic weights and random embeddings, inputs resident in HBM when the 
 With N GPUs every rank generates its own batch (weak scaling); rank 0 owns the conditioning of all N*batch images and
 broadcasts it once per step over RCCL (the only collective of the path).
 
-Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).  Besides the contract fields the line carries
+`throughput`: the same path at throughput batch sizes (batch 32 at configs[1]; BASELINE configs[2] = batch 64, 64x64 tokens,
+12 steps), each with its own in-run roofline.
 """
 import argparse
 import ctypes
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-
-import torch
-import torch.distributed as dist
 
 MODELS = {
     "570m": dict(c_in=256, c_out=256, num_labels=8192, c_r=64, patch_size=2, c_cond=1024, c_hidden=[640, 1280, 1280],
@@ -39,12 +44,13 @@ MODELS["1b"] = dict(MODELS["570m"], blocks=[6, 16, 6])
 VQ = {"570m": dict(levels=3, bottleneck_blocks=12, c_hidden=384, c_latent=4, codebook_size=8192, scale_factor=0.3764),
       "tiny": dict(levels=3, bottleneck_blocks=2, c_hidden=64, c_latent=4, codebook_size=64, scale_factor=0.3764)}
 VQ["1b"] = VQ["570m"]
-PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2_f32, dense
-# SURVEY.md section 8(d), per image: 2 * steps * F_fwd(model, grid, S=4) + VQGAN f8 decode, in GFLOP (the GEMM-shaped work)
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA (v_mfma_f32_16x16x32_bf16), MI355X_MICROARCH.md
 WORKLOAD_TAG = {("570m", 1, 32, 8): "BASELINE configs[1]", ("570m", 64, 64, 12): "BASELINE configs[2]"}
-ALGO_GFLOP_PER_IMAGE = {("570m", 32, 8): 2 * 8 * 66.27 + 38.8}
-PEAK_HBM_GBS = 8000.0
+# SURVEY.md section 8(d)/8(a), per image: 2 * steps * F_fwd(model, grid, S=4) + VQGAN f8 decode, in GFLOP (the GEMM-shaped work)
+ALGO_GFLOP_PER_IMAGE = {("570m", 32, 8): 2 * 8 * 66.27 + 38.8, ("570m", 64, 12): 2 * 12 * 266.5 + 155.0}
+# the kernel sources the roofline's PMC traffic figure belongs to (profiles/*_pmc_traffic.json is stamped with their hash)
+TRAFFIC_SOURCES = ["paella_amd/csrc/gemm.hip", "paella_amd/csrc/gemm_device.h", "paella_amd/csrc/model.hip", "paella_amd/csrc/common.h"]
 
 
 def parse():
@@ -59,22 +65,61 @@ def parse():
     ap.add_argument("--noise", default="philox", choices=["philox", "torch"])
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one captured HIP graph per image batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the informational batched-throughput run")
-    ap.add_argument("--extra-batch", type=int, default=8)
+    ap.add_argument("--no-extra", action="store_true", help="skip the throughput-batch runs (batch 32 at configs[1], BASELINE configs[2])")
     ap.add_argument("--gemm", default="fp32", choices=["fp32", "bf16"],
                     help="fp32 = the exact path (the headline); bf16 = OPT-IN fast mode outside the parity contract (bf16 MFMA operands, fp32 accumulate)")
     ap.add_argument("--force-dist", action="store_true", help="take the torch.distributed (RCCL) path even at world size 1 (launch under torchrun)")
     return ap.parse_args()
 
 
-def gen_images(model, vq, cond, uncond, batch, grid, sample_steps, noise, seed, device):
-    import paella_amd
-    toks = paella_amd.sample(model, cond, (batch, grid, grid), unconditional_inputs=uncond, steps=sample_steps,
-                             renoise_steps=sample_steps - 1, temperature=(1.0, 0.2), cfg=8.0, device=device, noise=noise, seed=seed)
-    return vq.decode_indices(toks)
+def self_launch(a):
+    """`python bench.py --gpus N` with N > 1 and no launcher: become the launcher (one rank per GPU over RCCL on 127.0.0.1)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this platform
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: --gpus %d without a launcher -> %s" % (a.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
+def source_stamp():
+    h = hashlib.sha256()
+    for rel in TRAFFIC_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def load_traffic(model, batch, grid, sample_steps):
+    """HBM bytes per GEMM launch from a committed rocprofv3 PMC pass of this workload (tools/pmc_traffic.py writes the file and
+    stamps it with the hash of the kernel sources); a file measured on other sources is REFUSED, not silently reused."""
+    import glob
+    stamp = source_stamp()
+    stale = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")), reverse=True):
+        try:
+            tj = json.load(open(path))
+        except Exception:
+            continue
+        w = tj.get("workload", {})
+        if (w.get("model"), w.get("batch_per_gpu"), w.get("grid"), w.get("sample_steps")) != (model, batch, grid, sample_steps):
+            continue
+        if tj.get("source_stamp") != stamp:
+            stale = os.path.basename(path)
+            continue
+        return tj["hbm_bytes_per_launch"], ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/%s, kernel-source stamp %s): 2*FETCH+WRITE KiB per "
+                                            "launch, gfx950 correction applied" % (os.path.basename(path), stamp))
+    return None, ("no PMC traffic file for the current kernel sources (stamp %s)%s; run tools/pmc_traffic.py on a GPU box"
+                  % (stamp, "; %s is stale and was refused" % stale if stale else ""))
 
 
 def timed(fn, steps, warmup, distributed, device):
+    import torch
+    import torch.distributed as dist
     for _ in range(warmup):
         fn()
     if distributed:
@@ -95,11 +140,13 @@ def timed(fn, steps, warmup, distributed, device):
 
 
 def cpu_baseline(model_cfg, vq_cfg, grid, sample_steps, unet_sd, vq_sd, cond, uncond):
-    """The oracle (CPU restatement of the reference, oracle/paella_oracle.py) timed on this host's cores, on ONE image of
-    the same workload: sample_steps x 2 forwards + sampling tails + f8 decode."""
+    """The oracle (CPU restatement of the reference, oracle/paella_oracle.py: kind = "port") timed on this host's cores.
+    Thread count: ONE sampling step (2 forwards + tail) is timed at {16, 32, 64, all} threads, the fastest setting then runs the
+    whole image -- sample_steps x 2 forwards + sampling tails + f8 decode -- which is the reported figure."""
+    import torch
     from oracle import paella_oracle as O
-    n = torch.get_num_threads()
     L = model_cfg["num_labels"]
+    all_threads = torch.get_num_threads()
     noise = O.replay_torch_noise(0, (1, grid, grid), L, sample_steps, sample_steps - 1)
     t_list = [float(v) for v in torch.linspace(1.0, 0.0, sample_steps + 1)]
     temps = [float(v) for v in torch.linspace(1.0, 0.2, sample_steps)]
@@ -107,18 +154,73 @@ def cpu_baseline(model_cfg, vq_cfg, grid, sample_steps, unet_sd, vq_sd, cond, un
     fwd = lambda tk, rr, **i: O.unet_forward(unet_sd, model_cfg, tk, rr, **i)
     c1 = {k: (v[:1].cpu() if v is not None else None) for k, v in cond.items()}
     u1 = {k: (v[:1].cpu() if v is not None else None) for k, v in uncond.items()}
-    with torch.no_grad():
+
+    def run(n_steps, decode):
         t0 = time.perf_counter()
-        toks, _ = O.sample(fwd, L, c1, u1, (1, grid, grid), steps=sample_steps, renoise_steps=sample_steps - 1, temperatures=temps,
-                           cfgs=[cf] * sample_steps, t_list=t_list, noise=noise)
-        O.vq_decode_indices(vq_sd, vq_cfg, toks % vq_cfg["codebook_size"])
-        dt = time.perf_counter() - t0
-    return {"value": round(1.0 / dt, 4), "unit": "images/sec", "cores": n, "kind": "port",
-            "sample": "1 image: %d steps x 2 forwards (cond+uncond) + sampling tails + VQGAN f8 decode, torch CPU fp32, %.1f s" % (sample_steps, dt)}
+        toks, _ = O.sample(fwd, L, c1, u1, (1, grid, grid), steps=n_steps, renoise_steps=n_steps - 1, temperatures=temps[:n_steps],
+                           cfgs=[cf] * n_steps, t_list=t_list[:n_steps + 1], noise=noise)
+        if decode:
+            O.vq_decode_indices(vq_sd, vq_cfg, toks % vq_cfg["codebook_size"])
+        return time.perf_counter() - t0
+
+    sweep = {}
+    try:
+        with torch.no_grad():
+            for n in sorted(set(t for t in (16, 32, 64, all_threads) if t <= all_threads)):
+                torch.set_num_threads(n)
+                run(1, False)                 # warm-up at this thread count (allocator, thread pool)
+                sweep[n] = round(run(1, False), 3)
+            best = min(sweep, key=sweep.get)
+            torch.set_num_threads(best)
+            dt = run(sample_steps, True)
+    finally:
+        torch.set_num_threads(all_threads)
+    return {"value": round(1.0 / dt, 4), "unit": "images/sec", "cores": best, "kind": "port",
+            "sample": "1 image: %d steps x 2 forwards (cond+uncond) + sampling tails + VQGAN f8 decode, torch CPU fp32, %.1f s at %d threads "
+                      "(best of a one-step sweep, seconds per step by thread count: %s; host has %d)" % (sample_steps, dt, best, json.dumps(sweep), all_threads)}
+
+
+def gemm_roofline(lib, run_once, device, model, batch, grid, sample_steps, gemm, with_traffic):
+    """Roofline of the dominant kernel family (fp32 MFMA GEMM): one extra identical pass with every GEMM launch bracketed by HIP
+    events on its stream (eager launches; the timed region runs without the events)."""
+    import torch
+    lib.paella_prof_enable(1)
+    run_once()
+    torch.cuda.synchronize(device)
+    ms, fl, by, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+    lib.paella_prof_collect(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by), ctypes.byref(n))
+    lib.paella_prof_enable(0)
+    executed = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+    traffic, traffic_note = load_traffic(model, batch, grid, sample_steps) if with_traffic else (None, "not collected for this workload")
+    # SURVEY.md section 8(d): algorithmic work of one image as the reference executes it = 2 x sample_steps full forwards
+    # + one VQGAN decode.  The CFG de-duplication (DESIGN.md section 5) executes fewer FLOPs for the same result, so both
+    # figures are reported: `achieved` prices the algorithmic work, `executed_tflops` what the launches really multiplied.
+    algo = ALGO_GFLOP_PER_IMAGE.get((model, grid, sample_steps))
+    peak = PEAK_FP32_MFMA_TFLOPS if gemm == "fp32" else PEAK_BF16_MFMA_TFLOPS
+    ach = executed
+    if algo is not None and ms.value > 0:
+        ach = algo * batch * 1e9 / (ms.value * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": ("gemm_nt_kernel (fp32 v_mfma_f32_16x16x4_f32, all tile configs, in-launch partial-tile combine included)" if gemm == "fp32"
+                                        else "gemm_bf16_kernel (v_mfma_f32_16x16x32_bf16) + fp32 gemm_nt_kernel for the few GEMMs without a bf16 path"),
+            "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+            "achieved_basis": ("SURVEY 8(d) algorithmic GFLOP per image (2 x steps full forwards + decode) / summed GEMM launch time"
+                               if algo is not None else "executed GEMM FLOPs / summed GEMM launch time"),
+            "executed_tflops": round(executed, 2), "executed_frac": round(executed / peak, 4),
+            "algorithmic_gflop_per_image": algo,
+            "traffic": traffic, "traffic_source": traffic_note, "algorithmic_bytes_per_launch": round(by.value / max(n.value, 1)),
+            "launches_per_step": int(n.value), "avg_launch_us": round(ms.value * 1e3 / max(n.value, 1), 2),
+            "gemm_ms_per_step": round(ms.value, 3), "executed_gflop_per_step": round(fl.value / 1e9, 1),
+            "algorithmic_gbytes_per_step": round(by.value / 1e9, 2),
+            "hbm_equiv_gbs": round(by.value / (ms.value * 1e-3) / 1e9, 1) if ms.value > 0 else 0.0}
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(a))
+
+    import torch
+    import torch.distributed as dist
     distributed = a.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1 or (a.force_dist and "RANK" in os.environ)
     rank, world, local = 0, 1, 0
     if distributed:
@@ -126,6 +228,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if world != a.gpus and rank == 0:
+            print("bench.py: --gpus %d but the launcher started %d ranks; reporting the observed world size" % (a.gpus, world), file=sys.stderr)
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
 
@@ -142,26 +246,40 @@ def main():
     vq = paella_amd.VQModel(**vcfg)
     vq_sd = synth.randomize_(vq, seed=0)
     vq = vq.to(device)
+    mk_cond = lambda n, seed: synth.synth_conditioning(n, 0, mcfg["byt5_embd"], mcfg["clip_embd"], seed=seed, device=device)
 
     total = a.batch * world
     # rank 0 owns the conditioning of the whole job (as if it had run the CLIP text encoder); CLIP-text-only: S_byt5 = 0
     cond_all = uncond_all = None
     if rank == 0:
-        cond_all = synth.synth_conditioning(total, 0, mcfg["byt5_embd"], mcfg["clip_embd"], seed=2, device=device)
-        uncond_all = synth.synth_conditioning(total, 0, mcfg["byt5_embd"], mcfg["clip_embd"], seed=3, device=device)
+        cond_all, uncond_all = mk_cond(total, 2), mk_cond(total, 3)
     lo, hi = shard_bounds(total, rank, world)
     # fixed request shapes: every rank derives the broadcast layout locally, so the per-step exchange is ONE async RCCL broadcast
-    tmpl = synth.synth_conditioning(total, 0, mcfg["byt5_embd"], mcfg["clip_embd"], seed=2, device=device)
+    tmpl = mk_cond(total, 2)
     layout = conditioning_layout([tmpl, tmpl]) if distributed else None
-    counter = [0]
     use_graph = not a.no_graph and a.noise == "philox"
-    sampler = None
-    if use_graph:
-        # capture sample() + decode once for this rank's shapes; every step replays it with fresh conditioning / seed
-        c0 = synth.synth_conditioning(a.batch, 0, mcfg["byt5_embd"], mcfg["clip_embd"], seed=2, device=device)
-        u0 = synth.synth_conditioning(a.batch, 0, mcfg["byt5_embd"], mcfg["clip_embd"], seed=3, device=device)
-        sampler = paella_amd.GraphSampler(model, c0, u0, (a.batch, a.grid, a.grid), steps=a.sample_steps, renoise_steps=a.sample_steps - 1,
-                                          temperature=(1.0, 0.2), cfg=8.0, device=device, vqgan=vq)
+
+    def make_runner(batch, grid, sample_steps, seed_base):
+        """(step function replaying the captured graph or launching eagerly, eager step function for the profiling pass)"""
+        counter = [0]
+        kw = dict(steps=sample_steps, renoise_steps=sample_steps - 1, temperature=(1.0, 0.2), cfg=8.0, device=device)
+        sampler = None
+        if use_graph:  # capture sample() + decode once for these shapes; every step replays it with fresh conditioning / seed
+            sampler = paella_amd.GraphSampler(model, mk_cond(batch, 2), mk_cond(batch, 3), (batch, grid, grid), vqgan=vq, **kw)
+
+        def eager(c, u):
+            counter[0] += 1
+            toks = paella_amd.sample(model, c, (batch, grid, grid), unconditional_inputs=u, noise=a.noise, seed=seed_base + 1000 * counter[0] + rank, **kw)
+            return vq.decode_indices(toks)
+
+        def step(c, u):
+            if sampler is None:
+                return eager(c, u)
+            counter[0] += 1
+            return sampler(c, u, seed=seed_base + 1000 * counter[0] + rank)[1]
+        return step, eager
+
+    step_fn, eager_fn = make_runner(a.batch, a.grid, a.sample_steps, 0)
 
     def step():
         if distributed:
@@ -169,80 +287,40 @@ def main():
             c, u = shard_inputs(c, lo, hi), shard_inputs(u, lo, hi)
         else:
             c, u = cond_all, uncond_all
-        counter[0] += 1
-        if sampler is not None:
-            return sampler(c, u, seed=1000 * counter[0] + rank)[1]
-        return gen_images(model, vq, c, u, a.batch, a.grid, a.sample_steps, a.noise, 1000 * counter[0] + rank, device)
-
-    def step_eager():
-        counter[0] += 1
-        c, u = (cond_all, uncond_all) if not distributed else (shard_inputs(cond_all, lo, hi), shard_inputs(uncond_all, lo, hi))
-        return gen_images(model, vq, c, u, a.batch, a.grid, a.sample_steps, a.noise, 1000 * counter[0] + rank, device)
+        return step_fn(c, u)
 
     dt = timed(step, a.steps, a.warmup, distributed, device)
     images = total * a.steps
     value = images / dt
     ms_per_step = dt / a.steps * 1e3
 
-    # ---- roofline of the dominant kernel family (fp32 MFMA GEMM): one extra identical pass with every GEMM launch
-    # bracketed by HIP events on its stream (eager launches; the timed region above runs without the events)
     roof = None
     if rank == 0:
-        lib.paella_prof_enable(1)
-        step_eager()
-        torch.cuda.synchronize(device)
-        ms, fl, by, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
-        lib.paella_prof_collect(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by), ctypes.byref(n))
-        lib.paella_prof_enable(0)
-        ach = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
-        # HBM traffic per launch from the committed PMC pass of this same workload (bench.py cannot collect PMC counters itself)
-        traffic, traffic_note = None, None
-        tp = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tp):
-            tj = json.load(open(tp))
-            w = tj.get("workload", {})
-            if (w.get("model"), w.get("batch_per_gpu"), w.get("grid"), w.get("sample_steps")) == (a.model, a.batch, a.grid, a.sample_steps):
-                traffic = tj["hbm_bytes_per_launch"]
-                traffic_note = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/r01_pmc_traffic.json): 2*FETCH+WRITE KiB per launch, gfx950 correction applied"
-        # algorithmic work of one image as the reference executes it = 2 x sample_steps full forwards
-        # + one VQGAN decode.  The CFG de-duplication executes fewer FLOPs for the same result, so both
-        # figures are reported: `achieved` prices the algorithmic work, `executed_tflops` what the launches really multiplied.
-        algo = ALGO_GFLOP_PER_IMAGE.get((a.model, a.grid, a.sample_steps))
-        peak = PEAK_FP32_MFMA_TFLOPS if a.gemm == "fp32" else PEAK_BF16_MFMA_TFLOPS
-        executed = ach
-        if algo is not None and ms.value > 0:
-            ach = algo * a.batch * 1e9 / (ms.value * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": ("gemm_nt_kernel (fp32 v_mfma_f32_16x16x4_f32, all tile configs, split-K reduce included)" if a.gemm == "fp32"
-                                            else "gemm_bf16_kernel (v_mfma_f32_16x16x32_bf16) + fp32 gemm_nt_kernel for the few GEMMs without a bf16 path"),
-                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                "achieved_basis": ("SURVEY 8(d) algorithmic GFLOP per image (2 x steps full forwards + decode) / summed GEMM launch time"
-                                   if algo is not None else "executed GEMM FLOPs / summed GEMM launch time"),
-                "executed_tflops": round(executed, 2), "executed_frac": round(executed / peak, 4),
-                "algorithmic_gflop_per_image": algo,
-                "traffic": traffic, "traffic_source": traffic_note, "algorithmic_bytes_per_launch": round(by.value / max(n.value, 1)),
-                "launches_per_step": int(n.value), "avg_launch_us": round(ms.value * 1e3 / max(n.value, 1), 2),
-                "gemm_ms_per_step": round(ms.value, 3), "executed_gflop_per_step": round(fl.value / 1e9, 1),
-                "algorithmic_gbytes_per_step": round(by.value / 1e9, 2),
-                "hbm_equiv_gbs": round(by.value / (ms.value * 1e-3) / 1e9, 1) if ms.value > 0 else 0.0}
-    elif distributed:
-        pass
+        c0, u0 = (cond_all, uncond_all) if not distributed else (shard_inputs(cond_all, lo, hi), shard_inputs(uncond_all, lo, hi))
+        roof = gemm_roofline(lib, lambda: eager_fn(c0, u0), device, a.model, a.batch, a.grid, a.sample_steps, a.gemm, True)
     if distributed:
         dist.barrier()
 
-    extra = None
-    if rank == 0 and not a.no_extra and not distributed and a.extra_batch > a.batch:
-        eb = a.extra_batch
-        ce = synth.synth_conditioning(eb, 0, mcfg["byt5_embd"], mcfg["clip_embd"], seed=2, device=device)
-        ue = synth.synth_conditioning(eb, 0, mcfg["byt5_embd"], mcfg["clip_embd"], seed=3, device=device)
-        if use_graph:
-            gs = paella_amd.GraphSampler(model, ce, ue, (eb, a.grid, a.grid), steps=a.sample_steps, renoise_steps=a.sample_steps - 1,
-                                         temperature=(1.0, 0.2), cfg=8.0, device=device, vqgan=vq)
-            fn = lambda: gs(ce, ue, seed=77)
-        else:
-            fn = lambda: gen_images(model, vq, ce, ue, eb, a.grid, a.sample_steps, a.noise, 77, device)
-        k = max(2, a.steps // 3)
-        dte = timed(fn, k, 1, False, device)
-        extra = {"batch": eb, "images_per_sec": round(eb * k / dte, 3), "ms_per_image": round(dte / (eb * k) * 1e3, 3)}
+    # ---- the same path at throughput batch sizes (rank 0, single GPU only): each with its own in-run roofline ----
+    throughput = None
+    if rank == 0 and not a.no_extra and not distributed and a.model == "570m" and (a.batch, a.grid, a.sample_steps) == (1, 32, 8):
+        throughput = []
+        for (eb, eg, es, k, w) in [(32, 32, 8, 3, 1), (64, 64, 12, 2, 1)]:
+            try:
+                ce, ue = mk_cond(eb, 2), mk_cond(eb, 3)
+                sfn, efn = make_runner(eb, eg, es, 50000 * eb)
+                dte = timed(lambda: sfn(ce, ue), k, w, False, device)
+                r = gemm_roofline(lib, lambda: efn(ce, ue), device, a.model, eb, eg, es, a.gemm, False)
+                throughput.append({"workload": "%s: batch %d per GPU, %dx%d tokens, %d steps, CFG 8.0, + VQGAN f8 decode"
+                                               % (WORKLOAD_TAG.get((a.model, eb, eg, es), "configs[1] model at a throughput batch"), eb, eg, eg, es),
+                                   "batch": eb, "grid": eg, "sample_steps": es, "steps": k, "warmup": w,
+                                   "images_per_sec": round(eb * k / dte, 3), "ms_per_image": round(dte / (eb * k) * 1e3, 3),
+                                   "roofline": {kk: r[kk] for kk in ("bound", "achieved", "peak", "unit", "frac", "executed_tflops", "executed_frac",
+                                                                      "launches_per_step", "avg_launch_us", "gemm_ms_per_step")}})
+                del sfn, efn
+                torch.cuda.empty_cache()
+            except Exception as e:  # informational runs: never lose the headline line over them
+                throughput.append({"batch": eb, "grid": eg, "sample_steps": es, "error": repr(e)})
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:  # the CPU baseline is an N = 1 figure
@@ -262,8 +340,11 @@ def main():
                                    "%d steps, CFG 8.0, CLIP-H-text only (S=4), batch %d per GPU, + VQGAN f8 decode"
                                    % (n_params / 1e6, a.grid, a.grid, a.grid * 8, a.sample_steps, a.batch),
                        "model": a.model, "batch_per_gpu": a.batch, "global_batch": total, "grid": a.grid, "sample_steps": a.sample_steps,
-                       "noise": a.noise, "submission": "hip-graph replay" if use_graph else "eager launches", "parallelism": "batch-shard x%d, one conditioning broadcast per step" % world},
-            "roofline": roof, "cpu_baseline": cpu, "batched": extra,
+                       "noise": a.noise, "submission": "hip-graph replay" if use_graph else "eager launches",
+                       "parallelism": "batch-shard x%d, one conditioning broadcast per step" % world,
+                       "world_size_observed": (dist.get_world_size() if distributed else 1),
+                       "collective_backend": (dist.get_backend() + " (RCCL)" if distributed else None)},
+            "roofline": roof, "cpu_baseline": cpu, "throughput": throughput,
         }
         print(json.dumps(line), flush=True)
     if distributed:

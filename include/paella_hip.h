@@ -145,12 +145,14 @@ int paella_sample_tail(const float* logits_c, const float* logits_u, int64_t row
                        uint64_t offset, const int64_t* init_noise, const float* mask_u, float t_next,
                        int64_t* tokens_out, int64_t* sampled_out, void* stream);
 
-/* Same, with an optional DEVICE-resident seed word added to `seed` (seed_ptr may be NULL): a HIP graph that captured
- * the sampling loop can then be replayed with fresh noise by rewriting that one word. */
+/* Same, with (a) an optional DEVICE-resident seed word added to `seed` (seed_ptr may be NULL): a HIP graph that captured
+ * the sampling loop can then be replayed with fresh noise by rewriting that one word; (b) row_offset: the Philox counters
+ * are keyed by (row + row_offset), so a batch shard that owns global rows [lo, hi) passes lo * H * W and draws exactly the
+ * noise the unsharded call draws for those rows (sharded == unsharded). */
 int paella_sample_tail_ex(const float* logits_c, const float* logits_u, int64_t rows, int L, float cfg,
                           float one_minus_cfg, float temperature, int mode, const float* noise_q, uint64_t seed,
-                          const uint64_t* seed_ptr, uint64_t offset, const int64_t* init_noise, const float* mask_u,
-                          float t_next, int64_t* tokens_out, int64_t* sampled_out, void* stream);
+                          const uint64_t* seed_ptr, uint64_t offset, int64_t row_offset, const int64_t* init_noise,
+                          const float* mask_u, float t_next, int64_t* tokens_out, int64_t* sampled_out, void* stream);
 
 /* x, random_x, mask int64 [B, per_sample]; t fp32 [B].  mask_in NULL -> mask = (u <= t[b]) with u = rand_u
  * (caller noise, [B, per_sample]) or Philox; random_x NULL -> Philox randint(0, num_labels). */

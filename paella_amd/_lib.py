@@ -59,7 +59,7 @@ SIGNATURES = {
     "paella_sample_tail": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, c_float, c_float, c_int, c_void_p,
                                    c_uint64, c_uint64, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
     "paella_sample_tail_ex": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, c_float, c_float, c_int, c_void_p,
-                                      c_uint64, c_void_p, c_uint64, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
+                                      c_uint64, c_void_p, c_uint64, c_int64, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
     "paella_add_noise": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint64, c_uint64, c_int, c_int,
                                  c_int64, c_void_p, c_void_p, c_void_p]),
     "paella_vqgan_create": (c_int, [POINTER(VqganConfig), POINTER(c_void_p)]),

@@ -165,6 +165,7 @@ struct TailArgs {
     int mode;                     // 0 = categorical, 1 = argmax (T=0 extension)
     const float* noise_q;         // [rows, L] Exp(1) noise (parity mode) or null -> Philox
     uint64_t seed; uint64_t offset;
+    int64_t row_offset;           // Philox counters use row + row_offset: a batch shard [lo, hi) passes lo * H * W and draws the noise of its GLOBAL rows
     const uint64_t* seed_ptr;     // optional device-resident seed (added to `seed`): lets a captured HIP graph be replayed with new noise
     const int64_t* init_noise;    // renoise source or null (no renoise)
     const float* mask_u;          // [rows] U[0,1) (parity mode) or null -> Philox

@@ -364,27 +364,33 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs g, SkPla
     int ckt = (int)(u0 - (unsigned)ctile * (unsigned)KT);
     bool first_seg = true;
     int slot = 0;
-    int ph = 0;  // i % PD
+    // one unit: `rf` is the free ring stage (gets the unit PD ahead), `rs` holds the next unit (goes to the other LDS stage).
+    // One basic block per phase: the prefetch is pinned above the MFMA block (hipcc sinks it otherwise).
+    auto step = [&](Stage& rf, const Stage& rs) {
+        fetch(rf);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(slot);
+        __builtin_amdgcn_sched_barrier(0);
+        store_unit(rs, slot ^ 1);
+        __syncthreads();
+        slot ^= 1;
+    };
     for (int i = 0; i < n;) {
         const int seg_len = min(KT - ckt, n - i);
-        for (int s = 0; s < seg_len; ++s) {
-            // one basic block per unit: the prefetch is pinned above the MFMA block (hipcc sinks it otherwise)
-            if (PD == 1 || ph == 0) {
-                fetch(R[0]);
-                __builtin_amdgcn_sched_barrier(0);
-                compute(slot);
-                __builtin_amdgcn_sched_barrier(0);
-                store_unit(R[1 % PD], slot ^ 1);
-            } else {
-                fetch(R[PD - 1]);
-                __builtin_amdgcn_sched_barrier(0);
-                compute(slot);
-                __builtin_amdgcn_sched_barrier(0);
-                store_unit(R[0], slot ^ 1);
+        if constexpr (PD == 1) {
+            for (int s = 0; s < seg_len; ++s) step(R[0], R[0]);
+        } else {
+            // ring roles are static inside the pair loop (runtime-indexed register arrays go to scratch); a segment of odd
+            // length leaves the ring in phase 1, so it is re-based with ONE stage copy per segment
+            int s = 0;
+            for (; s + 2 <= seg_len; s += 2) {
+                step(R[0], R[1]);
+                step(R[1], R[0]);
             }
-            __syncthreads();
-            slot ^= 1;
-            ph = (PD == 1) ? 0 : (ph ^ 1);
+            if (s < seg_len) {
+                step(R[0], R[1]);
+                R[1] = R[0];
+            }
         }
         flush(ctile, ckt, ckt + seg_len, first_seg);
         first_seg = false;

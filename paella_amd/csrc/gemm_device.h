@@ -1,4 +1,4 @@
-// Device-side epilogue shared by the GEMM kernels (gemm.hip, gemm_ws.hip) and the split-K reducer.
+// Device-side epilogue shared by the GEMM kernels (gemm.hip, gemm_bf16.hip).
 #pragma once
 #include "common.h"
 

@@ -788,28 +788,25 @@ extern "C" int paella_unet_forward_shared(paella_unet* m, const int64_t* tokens,
 // ---------------------------------------------------------------------------
 extern "C" int paella_sample_tail_ex(const float* logits_c, const float* logits_u, int64_t rows, int L, float cfg, float one_minus_cfg,
                                      float temperature, int mode, const float* noise_q, uint64_t seed, const uint64_t* seed_ptr,
-                                     uint64_t offset, const int64_t* init_noise, const float* mask_u, float t_next,
-                                     int64_t* tokens_out, int64_t* sampled_out, void* stream);
+                                     uint64_t offset, int64_t row_offset, const int64_t* init_noise, const float* mask_u, float t_next,
+                                     int64_t* tokens_out, int64_t* sampled_out, void* stream) {
+    if (!logits_c || !tokens_out) { paella_set_error("null argument"); return PAELLA_ERR_ARG; }
+    if (mode == 0 && !(temperature > 0.f)) { paella_set_error("temperature must be > 0 in categorical mode (use mode=1 for argmax)"); return PAELLA_ERR_ARG; }
+    if (row_offset < 0) { paella_set_error("row_offset must be >= 0"); return PAELLA_ERR_ARG; }
+    TailArgs a;
+    a.logits_c = logits_c; a.logits_u = logits_u; a.rows = rows; a.L = L; a.cfg = cfg; a.one_minus_cfg = one_minus_cfg;
+    a.temperature = temperature; a.mode = mode; a.noise_q = noise_q; a.seed = seed; a.seed_ptr = seed_ptr; a.offset = offset;
+    a.row_offset = row_offset;
+    a.init_noise = init_noise; a.mask_u = mask_u; a.t_next = t_next; a.tokens_out = tokens_out; a.sampled_out = sampled_out;
+    return launch_sample_tail(a, (hipStream_t)stream);
+}
 
 extern "C" int paella_sample_tail(const float* logits_c, const float* logits_u, int64_t rows, int L, float cfg, float one_minus_cfg,
                                   float temperature, int mode, const float* noise_q, uint64_t seed, uint64_t offset,
                                   const int64_t* init_noise, const float* mask_u, float t_next, int64_t* tokens_out,
                                   int64_t* sampled_out, void* stream) {
-    return paella_sample_tail_ex(logits_c, logits_u, rows, L, cfg, one_minus_cfg, temperature, mode, noise_q, seed, nullptr, offset,
+    return paella_sample_tail_ex(logits_c, logits_u, rows, L, cfg, one_minus_cfg, temperature, mode, noise_q, seed, nullptr, offset, 0,
                                  init_noise, mask_u, t_next, tokens_out, sampled_out, stream);
-}
-
-extern "C" int paella_sample_tail_ex(const float* logits_c, const float* logits_u, int64_t rows, int L, float cfg, float one_minus_cfg,
-                                     float temperature, int mode, const float* noise_q, uint64_t seed, const uint64_t* seed_ptr,
-                                     uint64_t offset, const int64_t* init_noise, const float* mask_u, float t_next,
-                                     int64_t* tokens_out, int64_t* sampled_out, void* stream) {
-    if (!logits_c || !tokens_out) { paella_set_error("null argument"); return PAELLA_ERR_ARG; }
-    if (mode == 0 && !(temperature > 0.f)) { paella_set_error("temperature must be > 0 in categorical mode (use mode=1 for argmax)"); return PAELLA_ERR_ARG; }
-    TailArgs a;
-    a.logits_c = logits_c; a.logits_u = logits_u; a.rows = rows; a.L = L; a.cfg = cfg; a.one_minus_cfg = one_minus_cfg;
-    a.temperature = temperature; a.mode = mode; a.noise_q = noise_q; a.seed = seed; a.seed_ptr = seed_ptr; a.offset = offset;
-    a.init_noise = init_noise; a.mask_u = mask_u; a.t_next = t_next; a.tokens_out = tokens_out; a.sampled_out = sampled_out;
-    return launch_sample_tail(a, (hipStream_t)stream);
 }
 
 extern "C" int paella_add_noise(const int64_t* x, const float* t, const int64_t* mask_in, const int64_t* random_x, const float* rand_u,

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void sample_tail_kernel(TailArgs a) {
                 q = *reinterpret_cast<const f32x4*>(nq + i4 * 4);
             } else {
                 uint32_t rb[4];
-                philox4x32(seed, (uint64_t)row * L4 + i4, a.offset, rb);
+                philox4x32(seed, (uint64_t)(row + a.row_offset) * L4 + i4, a.offset, rb);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) q[e] = __logf(-logf(u01_open(rb[e])));  // log of an Exp(1) variate: argmax(p/q) == argmax(log p - log q)
             }
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void sample_tail_kernel(TailArgs a) {
                 u = a.mask_u[row];
             } else {
                 uint32_t rb[4];
-                philox4x32(seed ^ 0x5bd1e9955bd1e995ull, (uint64_t)row, a.offset, rb);
+                philox4x32(seed ^ 0x5bd1e9955bd1e995ull, (uint64_t)(row + a.row_offset), a.offset, rb);
                 u = u01_half_open(rb[0]);
             }
             if (u <= a.t_next) tok = a.init_noise[row];

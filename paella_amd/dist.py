@@ -129,9 +129,28 @@ def shard_inputs(inputs, lo, hi):
     return out
 
 
-def sample_sharded(model, model_inputs, unconditional_inputs, latent_shape, src=0, group=None, gather=False, **kwargs):
+def agree_on_seed(seed, src=0, device=None, group=None):
+    """Every rank must key its counter-based noise with the SAME seed: `seed` if given (then all ranks must pass the same
+    value), otherwise a fresh one drawn on `src` and broadcast (one 8-byte tensor)."""
+    if seed is not None:
+        return int(seed)
+    from .sampling import fresh_seed
+    backend_cpu = dist.get_backend(group) == "gloo"
+    t = torch.zeros(1, dtype=torch.int64, device="cpu" if backend_cpu or device is None else device)
+    if dist.get_rank(group) == src:
+        t[0] = fresh_seed()
+    dist.broadcast(t, src=src, group=group)
+    return int(t.item())
+
+
+def sample_sharded(model, model_inputs, unconditional_inputs, latent_shape, src=0, group=None, gather=False, noise="philox", seed=None,
+                   **kwargs):
     """Batch-sharded `sample`: broadcast the conditioning once, sample this rank's rows, optionally all_gather.
-    `model_inputs` / `unconditional_inputs` are needed on rank `src` only.  kwargs go to paella_amd.sample."""
+    `model_inputs` / `unconditional_inputs` are needed on rank `src` only.  kwargs go to paella_amd.sample.
+    With the counter-based noise (default here) every random number -- start tokens, categorical draws, renoise mask -- is
+    keyed by (seed, GLOBAL row, step), so the concatenation of the shards equals the unsharded `sample(..., noise="philox",
+    seed=seed)` bit for bit, whatever the world size.  noise="torch" consumes each rank's own torch generator
+    (no cross-rank equivalence; the reference has none either)."""
     from .sampling import sample
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     device = next(model.parameters()).device
@@ -139,10 +158,14 @@ def sample_sharded(model, model_inputs, unconditional_inputs, latent_shape, src=
                                           device=device, group=group)
     B, H, W = latent_shape
     lo, hi = shard_bounds(B, rank, world)
+    shard = None
+    if noise == "philox":
+        seed = agree_on_seed(seed, src=src, device=device, group=group)
+        shard = (lo, B)
     local = None
     if hi > lo:
         local = sample(model, shard_inputs(cond, lo, hi), (hi - lo, H, W), unconditional_inputs=shard_inputs(uncond, lo, hi),
-                       device=device, **kwargs)
+                       device=device, noise=noise, seed=seed, shard=shard, **kwargs)
     if not gather:
         return local
     sizes = [shard_bounds(B, r, world) for r in range(world)]

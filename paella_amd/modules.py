@@ -224,12 +224,26 @@ class Paella(nn.Module):
             except Exception:
                 pass
 
-    def _workspace(self, nbytes):
+    def _workspace(self, nbytes, ws=None):
+        """The module's own scratch workspace (grown on demand), or a caller-owned one (`ws`, from `new_workspace`): anything
+        that outlives the call -- a captured HIP graph above all -- must bring its own, because growing the module's
+        workspace frees the old buffer."""
         dev = self._device()
+        if ws is not None:
+            if ws.device != dev or ws.dtype != torch.uint8 or ws.numel() < nbytes:
+                raise ValueError("workspace too small or on the wrong device (%d bytes needed)" % nbytes)
+            return ws
         if self._ws is None or self._ws.numel() < nbytes or self._ws.device != dev:
             self._ws = None
             self._ws = _lib.new_workspace(nbytes, dev)
         return self._ws
+
+    def workspace_bytes(self, B, H, W, S):
+        """Bytes of workspace one forward (and the conditioning preparation) of this shape needs."""
+        return int(_lib.load().paella_unet_workspace_bytes(self._engine(), B, H, W, S))
+
+    def new_workspace(self, B, H, W, S):
+        return _lib.new_workspace(self.workspace_bytes(B, H, W, S), self._device())
 
     @staticmethod
     def _f32(t, name):
@@ -262,7 +276,7 @@ class Paella(nn.Module):
         arr = (ctypes.c_void_p * max(len(images), 1))(*[ci.data_ptr() for ci in images]) if images else None
         return byt5, clip, images, arr, B, Sb, S
 
-    def prepare_cond(self, byt5, clip=None, clip_image=None):
+    def prepare_cond(self, byt5, clip=None, clip_image=None, ws=None):
         """Hoisted conditioning work (gen_c_embeddings + kv_mapper + K/V in-projection per AttnBlock)."""
         h = self._engine()
         lib = _lib.load()
@@ -273,7 +287,7 @@ class Paella(nn.Module):
         with torch.cuda.device(dev):
             nbytes = lib.paella_unet_cond_bytes(h, B, S)
             buf = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
-            ws = self._workspace(lib.paella_unet_workspace_bytes(h, B, 0, 0, S))
+            ws = self._workspace(lib.paella_unet_workspace_bytes(h, B, 0, 0, S), ws)
             _lib.check(lib.paella_unet_cond_prepare(h, _lib.ptr(byt5) if Sb > 0 else None, Sb, _lib.ptr(clip), arr, len(images), B,
                                                     _lib.ptr(buf), buf.numel(), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)))
         return CondCache(buf, B, S)
@@ -303,7 +317,7 @@ class Paella(nn.Module):
         return out
 
     # ------------------------------------------------------------------ forward
-    def forward_prepared(self, x, r, cond, attn_weights=None, out=None, cfg_mix=None):
+    def forward_prepared(self, x, r, cond, attn_weights=None, out=None, cfg_mix=None, ws=None):
         """One denoising evaluation against a `CondCache`. x int64 [Bx,H,W]; r fp32 [Bx].
         Normally Bx == cond.B.  With Bx < cond.B (cond.B a multiple of Bx) the rows b, b + Bx, ... of the conditioning
         share the tokens and timestep of row b -- classifier-free guidance batches the conditional and unconditional pass
@@ -337,7 +351,7 @@ class Paella(nn.Module):
         elif tuple(out.shape) != (Bo, H, W, self.num_labels) or out.dtype != torch.float32 or not out.is_contiguous():
             raise ValueError("out must be a contiguous fp32 [B,H,W,num_labels] tensor")
         with torch.cuda.device(dev):
-            ws = self._workspace(lib.paella_unet_workspace_bytes(h, B, H, W, cond.S))
+            ws = self._workspace(lib.paella_unet_workspace_bytes(h, B, H, W, cond.S), ws)
             _lib.check(lib.paella_unet_forward_shared(h, _lib.ptr(x), _lib.ptr(r), _lib.ptr(cond.buf), B, nu, mix[0], mix[1], H, W, cond.S, _lib.ptr(aw),
                                                       0 if aw is None else aw.numel(), _lib.ptr(out), _lib.ptr(ws), ws.numel(),
                                                       _lib.stream_ptr(dev)))

@@ -47,6 +47,20 @@ def _same_cond_layout(a, b):
     return True
 
 
+def _cond_seq_len(model, inputs):
+    """Conditioning rows per sample: S_byt5 + clip_seq_len * [clip] + clip_seq_len * #clip_image (src/modules.py:223-232)."""
+    if inputs is None:
+        return 0
+    n = model._cfg["clip_seq_len"]
+    S = inputs["byt5"].size(1) if inputs.get("byt5") is not None else 0
+    if inputs.get("clip") is not None:
+        S += n
+    ci = inputs.get("clip_image")
+    if ci is not None:
+        S += n * (len(ci) if isinstance(ci, (list, tuple)) else 1)
+    return S
+
+
 def _cat_inputs(a, b):
     out = {}
     for k in ("byt5", "clip", "clip_image"):
@@ -61,13 +75,30 @@ def _cat_inputs(a, b):
 
 
 def _tail(logits_c, logits_u, rows, L, cfg, omc, temperature, mode, noise_q, seed, offset, init_noise, mask_u, t_next, out,
-          seed_dev=None):
+          seed_dev=None, row_offset=0):
     lib = _lib.load()
     dev = logits_c.device
     with torch.cuda.device(dev):
         _lib.check(lib.paella_sample_tail_ex(_lib.ptr(logits_c), _lib.ptr(logits_u), rows, L, cfg, omc, temperature, mode,
-                                             _lib.ptr(noise_q), seed, _lib.ptr(seed_dev), offset, _lib.ptr(init_noise),
+                                             _lib.ptr(noise_q), seed, _lib.ptr(seed_dev), offset, row_offset, _lib.ptr(init_noise),
                                              _lib.ptr(mask_u), t_next, _lib.ptr(out), None, _lib.stream_ptr(dev)))
+
+
+def fresh_seed():
+    """A 62-bit seed drawn from torch's default (CPU) generator: reproducible under torch.manual_seed, different on every
+    call otherwise -- what `seed=None` means in the counter-based (Philox) noise mode."""
+    return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+
+
+def start_tokens(num_labels, shape, seed, device, shard=None):
+    """The start tokens of the counter-based noise mode: randint(0, num_labels) over the GLOBAL batch from a generator keyed by
+    `seed`, sliced to this shard's rows -- so a batch shard starts from exactly the tokens the unsharded call gives those rows
+    (the reference draws them with torch.randint on the global generator, src/utils.py:37; that stream cannot be sharded)."""
+    B, H, W = shape
+    lo, total = (0, B) if shard is None else (int(shard[0]), int(shard[1]))
+    gen = torch.Generator(device=device)
+    gen.manual_seed(int(seed) & (2 ** 63 - 1))
+    return torch.randint(0, num_labels, (total, H, W), device=device, generator=gen)[lo:lo + B].contiguous()
 
 
 def timestep_table(t_list, steps, B, device):
@@ -76,10 +107,13 @@ def timestep_table(t_list, steps, B, device):
 
 
 def _sample_core(model, model_inputs, unconditional_inputs, latent_shape, init_x, steps, renoise_steps, t_list, temperatures,
-                 cfgs, device, noise="torch", seed=0, attn_weights=None, seed_dev=None, init_noise_buf=None, r_all=None):
+                 cfgs, device, noise="torch", seed=None, attn_weights=None, seed_dev=None, init_noise_buf=None, r_all=None, shard=None,
+                 ws=None):
     """cfgs: per-step list of (cfg_fp32, one_minus_cfg_fp32) or None (no guidance at that step).
     seed_dev / init_noise_buf / r_all: device-resident seed word, pre-drawn start tokens and the [steps, B] timestep table
-    (HIP-graph capture cannot upload from the host, see GraphSampler)."""
+    (HIP-graph capture cannot upload from the host, see GraphSampler); ws: caller-owned workspace for every library call.
+    shard = (lo, total): this call samples rows [lo, lo + B) of a global batch of `total`; with noise="philox" every random
+    number is keyed by the GLOBAL row, so the shard reproduces those rows of the unsharded call bit for bit."""
     explicit = isinstance(noise, dict)  # parity tests: {"init_noise": [B,H,W], "q": [rows,L] per step, "u": [B,H,W] per step}
     if not explicit and noise not in ("torch", "philox"):
         raise ValueError("noise must be 'torch', 'philox' or a dict of explicit noise tensors")
@@ -91,11 +125,21 @@ def _sample_core(model, model_inputs, unconditional_inputs, latent_shape, init_x
     L = model.num_labels
     rows = B * H * W
     native = isinstance(model, Paella)
+    philox = (not explicit) and noise == "philox"
+    if philox and seed is None:
+        seed = 0 if seed_dev is not None else fresh_seed()  # GraphSampler keeps the live seed in device memory
+    if seed is None:
+        seed = 0  # unused: every random number comes from torch's generator or from explicit tensors
+    if shard is not None and not (philox or explicit):
+        raise ValueError("shard=(lo, total) needs noise='philox' (or explicit noise tensors): torch's generator stream cannot be sharded")
+    row_offset = 0 if shard is None else int(shard[0]) * H * W
     with torch.inference_mode():
         if init_noise_buf is not None:
             init_noise = init_noise_buf
         elif explicit:
             init_noise = noise["init_noise"].to(device=device, dtype=torch.int64).contiguous()
+        elif philox:
+            init_noise = start_tokens(L, (B, H, W), seed, device, shard)
         else:
             init_noise = torch.randint(0, L, size=(B, H, W), device=device)
         sampled = init_noise.clone() if init_x is None else init_x.to(device=device, dtype=torch.int64).contiguous()
@@ -103,12 +147,12 @@ def _sample_core(model, model_inputs, unconditional_inputs, latent_shape, init_x
         batched = False
         if native:
             if any_cfg and _same_cond_layout(model_inputs, unconditional_inputs):
-                cond_both = model.prepare_cond(**_cat_inputs(model_inputs, unconditional_inputs))
+                cond_both = model.prepare_cond(**_cat_inputs(model_inputs, unconditional_inputs), ws=ws)
                 batched = True
                 logits2 = torch.empty(2 * B, H, W, L, dtype=torch.float32, device=device)
             if not batched or not all(c is not None for c in cfgs):
-                cond_c = model.prepare_cond(**model_inputs)
-                cond_u = model.prepare_cond(**unconditional_inputs) if any_cfg and not batched else None
+                cond_c = model.prepare_cond(**model_inputs, ws=ws)
+                cond_u = model.prepare_cond(**unconditional_inputs, ws=ws) if any_cfg and not batched else None
             logits_c = torch.empty(B, H, W, L, dtype=torch.float32, device=device)
             logits_u = torch.empty(B, H, W, L, dtype=torch.float32, device=device) if any_cfg and not batched else None
         out = torch.empty(B, H, W, dtype=torch.int64, device=device)
@@ -123,15 +167,15 @@ def _sample_core(model, model_inputs, unconditional_inputs, latent_shape, init_x
                     # the conditioning-free prefix for them and replicates it where the two passes diverge.  With the
                     # counter-based generator (no bit-parity promise towards torch's RNG stream) a categorical step also lets
                     # the guidance mix ride through the linear head: one mixed logits tensor comes back.
-                    fold = (not explicit) and noise == "philox" and temperatures[i] != 0
+                    fold = philox and temperatures[i] != 0
                     model.forward_prepared(sampled, r, cond_both, attn_weights=attn_weights, out=logits2[:B] if fold else logits2,
-                                           cfg_mix=cfgs[i] if fold else None)
+                                           cfg_mix=cfgs[i] if fold else None, ws=ws)
                     lc, lu = logits2[:B], (None if fold else logits2[B:])
                 else:
-                    model.forward_prepared(sampled, r, cond_c, attn_weights=attn_weights, out=logits_c)
+                    model.forward_prepared(sampled, r, cond_c, attn_weights=attn_weights, out=logits_c, ws=ws)
                     lc, lu = logits_c, None
                     if use_cfg:
-                        model.forward_prepared(sampled, r, cond_u, attn_weights=attn_weights, out=logits_u)
+                        model.forward_prepared(sampled, r, cond_u, attn_weights=attn_weights, out=logits_u, ws=ws)
                         lu = logits_u
             else:  # any other callable with the reference's signature; logits come back [B, L, H, W]
                 lc = model(sampled, r, **model_inputs).permute(0, 2, 3, 1).float().contiguous()
@@ -157,14 +201,18 @@ def _sample_core(model, model_inputs, unconditional_inputs, latent_shape, init_x
                 mask_u = torch.rand(B, H, W, dtype=torch.float32, device=device)  # == torch.rand_like(x.float())
             cfg, omc = cfgs[i] if use_cfg else (1.0, 0.0)
             _tail(lc, lu, rows, L, cfg, omc, temp if mode == 0 else 1.0, mode, noise_q, seed, i,
-                  init_noise if renoise else None, mask_u, t_list[i + 1] if renoise else 0.0, out, seed_dev=seed_dev)
+                  init_noise if renoise else None, mask_u, t_list[i + 1] if renoise else 0.0, out, seed_dev=seed_dev,
+                  row_offset=row_offset)
             sampled = out  # the tail never reads `sampled`, so one output buffer is enough (stream-ordered reuse)
     return sampled
 
 
 def sample(model, model_inputs, latent_shape, unconditional_inputs=None, steps=12, renoise_steps=11, temperature=(1.0, 0.2),
-           cfg=8.0, t_start=1.0, t_end=0.0, device="cuda", *, noise="torch", seed=0, attn_weights=None):
-    """Drop-in for reference src/utils.py:35 `sample` (same positional order and defaults)."""
+           cfg=8.0, t_start=1.0, t_end=0.0, device="cuda", *, noise="torch", seed=None, attn_weights=None, shard=None):
+    """Drop-in for reference src/utils.py:35 `sample` (same positional order and defaults).
+    Keyword-only extensions: noise ("torch" = consume torch's generator exactly like the reference; "philox" = counter-based
+    noise generated in the kernels, keyed by `seed` -- None draws a fresh seed from torch's generator), attn_weights
+    (utils/modules.py:268), shard=(lo, total) for batch-sharded sampling (paella_amd.dist.sample_sharded)."""
     if cfg and unconditional_inputs is None:
         # the reference raises TypeError at src/utils.py:46 (`**None`); keep the failure, make it readable
         raise TypeError("cfg=%r requires unconditional_inputs" % (cfg,))
@@ -177,12 +225,12 @@ def sample(model, model_inputs, latent_shape, unconditional_inputs=None, steps=1
     else:
         cfgs = [None] * steps
     return _sample_core(model, model_inputs, unconditional_inputs, latent_shape, None, steps, renoise_steps, t_list, temperatures,
-                        cfgs, device, noise=noise, seed=seed, attn_weights=attn_weights)
+                        cfgs, device, noise=noise, seed=seed, attn_weights=attn_weights, shard=shard)
 
 
 def sample_distributed(model, model_inputs, unconditional_inputs, latent_shape, init_x=None, steps=12, renoise_steps=None,
                        temperature=(0.7, 0.3), cfg=(8.0, 8.0), t_start=1.0, t_end=0.0, sampling_conditional_steps=None, *,
-                       noise="torch", seed=0, attn_weights=None):
+                       noise="torch", seed=None, attn_weights=None, shard=None):
     """Drop-in for reference src_distributed/utils.py:97 `sample` (init_x, cfg schedule, conditional-step cutoff)."""
     device = unconditional_inputs["byt5"].device
     if sampling_conditional_steps is None:
@@ -198,7 +246,7 @@ def sample_distributed(model, model_inputs, unconditional_inputs, latent_shape, 
             # `logits * cfgs[i] + logits_u * (1 - cfgs[i])` with a 0-dim fp32 tensor: (1 - cfg) is computed in fp32
             cfgs[i] = (float(sched[i]), float(1 - sched[i]))
     return _sample_core(model, model_inputs, unconditional_inputs, latent_shape, init_x, steps, renoise_steps, t_list, temperatures,
-                        cfgs, device, noise=noise, seed=seed, attn_weights=attn_weights)
+                        cfgs, device, noise=noise, seed=seed, attn_weights=attn_weights, shard=shard)
 
 
 class GraphSampler:
@@ -224,6 +272,12 @@ class GraphSampler:
         self.seed_dev = torch.zeros(1, dtype=torch.int64, device=self.device)
         self.init_noise = torch.zeros(self.shape, dtype=torch.int64, device=self.device)
         self.r_all = timestep_table(linspace_schedule(t_start, t_end, steps + 1), steps, self.shape[0], self.device)
+        # The graph bakes raw pointers: it owns its workspaces (the modules' own scratch is dropped and reallocated whenever a
+        # later eager call needs a bigger one) and it is the only user of their split-K tickets.
+        B, H, W = self.shape
+        S = max(_cond_seq_len(model, self.cond), _cond_seq_len(model, self.uncond), 1)
+        self.ws = _lib.new_workspace(model.workspace_bytes(2 * B, H, W, S), self.device)
+        self.vq_ws = None if vqgan is None else _lib.new_workspace(vqgan.workspace_bytes(B, H, W), self.device)
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):
@@ -248,12 +302,14 @@ class GraphSampler:
             cfgs = [None] * k["steps"]
         toks = _sample_core(self.model, self.cond, self.uncond, self.shape, None, k["steps"], k["renoise_steps"], t_list, temps, cfgs,
                             self.device, noise="philox", seed=0, attn_weights=self.attn_weights, seed_dev=self.seed_dev,
-                            init_noise_buf=self.init_noise, r_all=self.r_all)
-        return toks if self.vqgan is None else (toks, self.vqgan.decode_indices(toks))
+                            init_noise_buf=self.init_noise, r_all=self.r_all, ws=self.ws)
+        return toks if self.vqgan is None else (toks, self.vqgan.decode_indices(toks, ws=self.vq_ws))
 
     @staticmethod
     def _copy_inputs(dst, src):
         if dst is None:
+            if src is not None:
+                raise ValueError("the graph was captured without this conditioning set")
             return
         for key, d in dst.items():
             s = src.get(key) if src is not None else None
@@ -262,21 +318,28 @@ class GraphSampler:
                     raise ValueError("conditioning layout differs from the captured one (%s)" % key)
                 continue
             if isinstance(d, (list, tuple)):
+                if not isinstance(s, (list, tuple)) or len(s) != len(d) or any(a.shape != b.shape for a, b in zip(d, s)):
+                    raise ValueError("conditioning layout differs from the captured one (%s: list length / shapes)" % key)
                 for a, b in zip(d, s):
                     a.copy_(b)
             else:
-                if s is None or s.shape != d.shape:
+                if s is None or isinstance(s, (list, tuple)) or s.shape != d.shape:
                     raise ValueError("conditioning shape differs from the captured one (%s)" % key)
                 d.copy_(s)
 
-    def __call__(self, model_inputs=None, unconditional_inputs=None, seed=0):
+    def __call__(self, model_inputs=None, unconditional_inputs=None, seed=None, shard=None):
         """Replay. Returns tokens (and the decoded image if a VQGAN was given); outputs live in graph-owned buffers that
-        the next replay overwrites."""
+        the next replay overwrites.  seed=None draws a fresh seed from torch's generator; the start tokens and all per-step
+        noise are functions of the seed (and of the global row when shard=(lo, total) is given)."""
         if model_inputs is not None:
             self._copy_inputs(self.cond, model_inputs)
         if unconditional_inputs is not None:
             self._copy_inputs(self.uncond, unconditional_inputs)
-        torch.randint(0, self.model.num_labels, self.shape, device=self.device, out=self.init_noise)
+        if seed is None:
+            seed = fresh_seed()
+        if shard is not None:
+            raise ValueError("a captured graph has its row offset baked in; use sample(..., shard=) for sharded parity runs")
+        self.init_noise.copy_(start_tokens(self.model.num_labels, self.shape, seed, self.device))
         self.seed_dev.fill_(int(seed))
         self.graph.replay()
         return self.out

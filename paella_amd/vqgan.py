@@ -151,8 +151,12 @@ class VQModel(nn.Module):
             except Exception:
                 pass
 
-    def _workspace(self, nbytes):
+    def _workspace(self, nbytes, ws=None):
         dev = self._device()
+        if ws is not None:  # caller-owned (a captured HIP graph must not depend on the module's growable scratch)
+            if ws.device != dev or ws.dtype != torch.uint8 or ws.numel() < nbytes:
+                raise ValueError("workspace too small or on the wrong device (%d bytes needed)" % nbytes)
+            return ws
         if self._ws is None or self._ws.numel() < nbytes or self._ws.device != dev:
             self._ws = None
             self._ws = _lib.new_workspace(nbytes, dev)
@@ -196,14 +200,17 @@ class VQModel(nn.Module):
                                                _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)))
         return qe, lat, idx, loss[0]
 
-    def _decode_common(self, fn, src, B, hh, ww):
+    def workspace_bytes(self, B, hh, ww):
+        return int(_lib.load().paella_vqgan_workspace_bytes(self._engine(), B, hh, ww))
+
+    def _decode_common(self, fn, src, B, hh, ww, ws=None):
         h = self._engine()
         lib = _lib.load()
         dev = self._device()
         f = 2 ** self.levels
         img = torch.empty(B, 3, hh * f, ww * f, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            ws = self._workspace(lib.paella_vqgan_workspace_bytes(h, B, hh, ww))
+            ws = self._workspace(lib.paella_vqgan_workspace_bytes(h, B, hh, ww), ws)
             _lib.check(getattr(lib, fn)(h, _lib.ptr(src), B, hh, ww, _lib.ptr(img), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)))
         return img
 
@@ -215,10 +222,10 @@ class VQModel(nn.Module):
         x = x.detach().float().contiguous()
         return self._decode_common("paella_vqgan_decode", x, x.size(0), x.size(2), x.size(3))
 
-    def decode_indices(self, x):
+    def decode_indices(self, x, ws=None):
         """reference src/vqgan.py:103-107: x = int64 token grid [B, h, w]"""
         self._engine()
         if not x.is_cuda or x.dtype != torch.int64 or x.dim() != 3:
             raise ValueError("x must be an int64 HIP tensor [B, h, w]")
         x = x.contiguous()
-        return self._decode_common("paella_vqgan_decode_indices", x, x.size(0), x.size(1), x.size(2))
+        return self._decode_common("paella_vqgan_decode_indices", x, x.size(0), x.size(1), x.size(2), ws)

@@ -9,57 +9,105 @@ import paella_amd
 from oracle import golden_configs as G
 from oracle import paella_oracle as O
 from paella_amd import sampling
-from tests.helpers import cond_for, to_dev, weights_for
+from tests.helpers import assert_token_parity, cond_for, stepwise_token_parity, to_dev, weights_for
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
 @pytest.fixture(scope="module")
-def tiny(golden, built_lib):
+def tiny_sd(golden, built_lib):
     m = paella_amd.Paella(**G.UNET_TINY)
-    weights_for(m, sum(G.UNET_TINY["blocks"]), golden("unet_tiny_forward"))
-    return m.to(DEV)
+    sd = weights_for(m, sum(G.UNET_TINY["blocks"]), golden("unet_tiny_forward"))
+    return m.to(DEV), sd
 
 
-def test_sample_reproduces_reference_tokens(golden, tiny):
-    """BASELINE config 1: tiny model, 32x32 grid, 8 steps, batch 1, CFG 8 -- reference src/utils.py:35 signature."""
+@pytest.fixture(scope="module")
+def tiny(tiny_sd):
+    return tiny_sd[0]
+
+
+def _oracle_fwd(sd, cfg):
+    def fwd(tk, rr, **inp):
+        with torch.no_grad():
+            return O.unet_forward(sd, cfg, tk, rr, **inp)
+    return fwd
+
+
+def _assert_rows_match_up_to_near_ties(m, part, full_rows, start_rows, cond2, uncond2, cfg_scale, eps=2e-3):
+    """Argmax step at sizes the oracle cannot reach: rows sampled as a small shard vs the same rows of the full batch.  Different
+    GEMM decompositions (M differs) change the fp32 summation order, so a token may differ ONLY where the mixed logits' top-1 /
+    top-2 margin is below eps; such positions are counted and printed."""
+    mism = part != full_rows
+    n_mis = int(mism.sum())
+    if n_mis:
+        r = torch.ones(start_rows.size(0), device=DEV)
+        l = m(start_rows, r, **cond2) * cfg_scale + m(start_rows, r, **uncond2) * (1.0 - cfg_scale)
+        top = l.topk(2, dim=1).values
+        margin = (top[:, 0] - top[:, 1])
+        clear = int((mism & ~(margin < eps)).sum())
+        print("shard vs full batch: %d / %d tokens differ, all at top1-top2 margin < %g: %s (max margin among them %.2e)"
+              % (n_mis, mism.numel(), eps, clear == 0, float(margin[mism].max())))
+        assert clear == 0, "%d token(s) differ where the logits were not a near-tie" % clear
+    else:
+        print("shard vs full batch: all %d tokens identical" % mism.numel())
+
+
+def _exact_or_counted(toks, ref_tokens, rep, what):
+    """Closed loop: identical integers, unless the teacher-forced run already counted near-tie flips (then the trajectories
+    may legitimately separate from that step on and the agreement is reported, not asserted)."""
+    same = int((toks.cpu().numpy() == ref_tokens).sum())
+    print("%s closed loop: %d / %d tokens identical to the reference" % (what, same, ref_tokens.size))
+    if rep["near_tie"] == 0:
+        assert same == ref_tokens.size, "%s: closed-loop tokens differ although no step had a near-tie flip" % what
+
+
+def test_sample_reproduces_reference_tokens(golden, tiny_sd):
+    """BASELINE config 1: tiny model, 32x32 grid, 8 steps, batch 1, CFG 8 -- reference src/utils.py:35 signature.
+    Bit-exact token parity: per step (teacher-forced on the oracle trajectory) every differing token must sit on a
+    reference near-tie; with no such flip the closed-loop grid equals the tokens the REFERENCE's own sample() produced."""
+    tiny, sd = tiny_sd
     g = golden("sample_tiny")
     cfg = G.UNET_TINY
-    cs, us = to_dev(cond_for(cfg, 1, 4, 0, G.COND_SEED), DEV), to_dev(cond_for(cfg, 1, 4, 0, G.COND_SEED + 5), DEV)
+    c, u = cond_for(cfg, 1, 4, 0, G.COND_SEED), cond_for(cfg, 1, 4, 0, G.COND_SEED + 5)
+    cs, us = to_dev(c, DEV), to_dev(u, DEV)
     noise = O.replay_torch_noise(G.SAMPLER_SEED, (1, 32, 32), cfg["num_labels"], 8, 7)
+    rep = stepwise_token_parity(tiny, _oracle_fwd(sd, cfg), cfg["num_labels"], c, u, cs, us, noise, 8, 7, (1.0, 0.2), 8.0)
+    assert_token_parity(rep, "tiny categorical, 8 steps")
     toks = paella_amd.sample(tiny, cs, (1, 32, 32), unconditional_inputs=us, steps=8, renoise_steps=7, temperature=(1.0, 0.2), cfg=8.0,
                              device=DEV, noise=noise)
     assert toks.dtype == torch.int64 and toks.shape == (1, 32, 32)
-    agree = (toks.cpu().numpy() == g["tokens"]).mean()
-    print("closed-loop categorical sample vs reference: %.4f of 1024 tokens identical" % agree)
-    assert agree >= 0.99, "closed-loop trajectory diverged from the reference (%.4f)" % agree
+    _exact_or_counted(toks, g["tokens"], rep, "categorical sample vs reference")
 
 
-def test_sample_argmax_trajectory(golden, tiny):
+def test_sample_argmax_trajectory(golden, tiny_sd):
     """T = 0 extension: argmax substituted for multinomial; final grid equals the oracle's closed-loop argmax trajectory."""
+    tiny, sd = tiny_sd
     g = golden("sample_tiny")
     cfg = G.UNET_TINY
-    cs, us = to_dev(cond_for(cfg, 1, 4, 0, G.COND_SEED), DEV), to_dev(cond_for(cfg, 1, 4, 0, G.COND_SEED + 5), DEV)
+    c, u = cond_for(cfg, 1, 4, 0, G.COND_SEED), cond_for(cfg, 1, 4, 0, G.COND_SEED + 5)
+    cs, us = to_dev(c, DEV), to_dev(u, DEV)
     noise = O.replay_torch_noise(G.SAMPLER_SEED, (1, 32, 32), cfg["num_labels"], 8, 7)
+    rep = stepwise_token_parity(tiny, _oracle_fwd(sd, cfg), cfg["num_labels"], c, u, cs, us, noise, 8, 7, (0.0, 0.0), 8.0, argmax=True, eps=1e-4)
+    assert_token_parity(rep, "tiny argmax, 8 steps")
     toks = paella_amd.sample(tiny, cs, (1, 32, 32), unconditional_inputs=us, steps=8, renoise_steps=7, temperature=(0.0, 0.0), cfg=8.0,
                              device=DEV, noise=noise)
-    agree = (toks.cpu().numpy() == g["tokens_argmax"]).mean()
-    print("closed-loop argmax sample vs oracle: %.4f identical" % agree)
-    assert agree >= 0.99
+    _exact_or_counted(toks, g["tokens_argmax"], rep, "argmax sample vs oracle")
 
 
 def test_sample_distributed_signature(golden, tiny):
-    """src_distributed/utils.py:97 variant: init_x, cfg schedule, conditional-step cutoff, different S for the uncond set."""
+    """src_distributed/utils.py:97 variant: init_x, cfg schedule, conditional-step cutoff, different S for the uncond set.
+    Closed loop against the REFERENCE's tokens; a difference is accepted only if a per-step rerun from the reference-side state
+    classifies it as a near-tie (same policy as above, printed)."""
     g = golden("sample_tiny_distributed")
     cfg = G.UNET_TINY
     cd, ud = to_dev(cond_for(cfg, 2, 5, 1, G.COND_SEED), DEV), to_dev(cond_for(cfg, 2, 2, 0, G.COND_SEED + 5), DEV)
     noise = O.replay_torch_noise(G.SAMPLER_SEED + 1, (2, 16, 16), cfg["num_labels"], 6, 5)
     toks = paella_amd.sample_distributed(tiny, cd, ud, (2, 16, 16), init_x=torch.from_numpy(g["init_x"]).to(DEV), steps=6,
                                          temperature=(0.7, 0.3), cfg=(8.0, 4.0), t_start=0.8, sampling_conditional_steps=4, noise=noise)
-    agree = (toks.cpu().numpy() == g["tokens"]).mean()
-    print("sample_distributed vs reference: %.4f identical" % agree)
-    assert agree >= 0.99
+    same = int((toks.cpu().numpy() == g["tokens"]).sum())
+    print("sample_distributed vs reference: %d / %d tokens identical" % (same, g["tokens"].size))
+    assert same == g["tokens"].size, "closed-loop tokens differ from the reference's (run the stepwise check to classify)"
 
 
 def test_noise_modes_and_seeding(tiny):
@@ -189,10 +237,15 @@ def test_config3_full_size_step_properties(built_lib):
     assert torch.equal(full, run(cs, us, noise_full, B))
     from paella_amd.dist import shard_inputs
     for lo in (0, 31, 62):
-        part = run(shard_inputs(cs, lo, lo + 2), shard_inputs(us, lo, lo + 2), {"init_noise": init[lo:lo + 2], "q": [None], "u": [u[lo:lo + 2]]}, 2)
-        same = (part == full[lo:lo + 2]).float().mean().item()
-        # different GEMM tilings at M = 2 x 1024 vs 128 x 1024 rows change fp32 summation order: argmax may flip at near-ties only
-        assert same >= 0.999, same
+        c2, u2 = shard_inputs(cs, lo, lo + 2), shard_inputs(us, lo, lo + 2)
+        # renoise off for the comparison run: the drawn tokens themselves are compared
+        nz = lambda sl: {"init_noise": init[sl], "q": [None], "u": [None]}
+        run0 = lambda c, un, n, b: paella_amd.sample(m, c, (b, H, H), unconditional_inputs=un, steps=1, renoise_steps=0, temperature=(0.0, 0.0),
+                                                     cfg=8.0, device=DEV, noise=n)
+        if lo == 0:
+            full0 = run0(cs, us, nz(slice(0, B)), B)
+        part = run0(c2, u2, nz(slice(lo, lo + 2)), 2)
+        _assert_rows_match_up_to_near_ties(m, part, full0[lo:lo + 2], init[lo:lo + 2].to(DEV), c2, u2, 8.0)
     x = full[:2].contiguous()
     r = torch.tensor([0.5, 0.25], device=DEV)
     c2 = shard_inputs(cs, 0, 2)
@@ -222,9 +275,10 @@ def test_config4_full_size_step_properties(built_lib):
     assert full.shape == (B, H, H) and int(full.min()) >= 0 and int(full.max()) < L
     assert torch.equal(full, run(cs, us, 0, B))
     from paella_amd.dist import shard_inputs
-    part = run(shard_inputs(cs, 30, 32), shard_inputs(us, 30, 32), 30, 32)
-    same = (part == full[30:32]).float().mean().item()
-    assert same >= 0.999, same
+    run0 = lambda c, un, lo, hi: paella_amd.sample(m, c, (hi - lo, H, H), unconditional_inputs=un, steps=1, renoise_steps=0, temperature=(0.0, 0.0),
+                                                   cfg=8.0, device=DEV, noise={"init_noise": init[lo:hi], "q": [None], "u": [None]})
+    c2, u2 = shard_inputs(cs, 30, 32), shard_inputs(us, 30, 32)
+    _assert_rows_match_up_to_near_ties(m, run0(c2, u2, 30, 32), run0(cs, us, 0, B)[30:32], init[30:32].to(DEV), c2, u2, 8.0)
     torch.cuda.empty_cache()
 
 
@@ -254,3 +308,111 @@ def test_config5_full_size_inpaint_properties(built_lib):
     assert torch.equal(toks[~mk], orig[~mk])
     assert (toks[mk] != orig[mk]).float().mean() > 0.2
     torch.cuda.empty_cache()
+
+
+def test_570m_closed_loop_three_steps_vs_oracle(built_lib):
+    """BASELINE configs[1] model size: 570M-class stand-in, 32x32 tokens, batch 1, CFG 8, CLIP-text only -- three sampling steps
+    with explicit noise against the CPU oracle (src/utils.py:35-55).  Per step every token must equal the oracle's draw unless
+    the oracle's own decision was a near-tie (counted); with no such flip the closed-loop result is bit-identical."""
+    cfg = G.UNET_570M
+    m = paella_amd.Paella(**cfg)
+    sd = weights_for(m, sum(cfg["blocks"]))
+    m = m.to(DEV)
+    c, u = cond_for(cfg, 1, 0, 0, G.COND_SEED), cond_for(cfg, 1, 0, 0, G.COND_SEED + 5)
+    cs, us = to_dev(c, DEV), to_dev(u, DEV)
+    steps = 3
+    noise = O.replay_torch_noise(G.SAMPLER_SEED, (1, 32, 32), cfg["num_labels"], steps, steps - 1)
+    fwd = _oracle_fwd(sd, cfg)
+    rep = stepwise_token_parity(m, fwd, cfg["num_labels"], c, u, cs, us, noise, steps, steps - 1, (1.0, 0.2), 8.0)
+    assert_token_parity(rep, "570M categorical, 3 steps")
+    t_list = [float(v) for v in torch.linspace(1.0, 0.0, steps + 1)]
+    temps = [float(v) for v in torch.linspace(1.0, 0.2, steps)]
+    with torch.no_grad():
+        otoks, _ = O.sample(fwd, cfg["num_labels"], c, u, (1, 32, 32), steps=steps, renoise_steps=steps - 1, temperatures=temps,
+                            cfgs=[(8.0, -7.0)] * steps, t_list=t_list, noise=noise)
+    toks = paella_amd.sample(m, cs, (1, 32, 32), unconditional_inputs=us, steps=steps, renoise_steps=steps - 1, temperature=(1.0, 0.2), cfg=8.0,
+                             device=DEV, noise=noise)
+    _exact_or_counted(toks, otoks.numpy(), rep, "570M 3-step sample vs oracle")
+
+
+def test_570m_benchmarked_path_vs_unfused(built_lib):
+    """What bench.py times -- shared CFG prefix + guidance mix folded through the linear head + in-kernel Philox noise -- against the
+    reference's order of operations (two full evaluations, mix afterwards) on the SAME Philox noise: tokens must be identical
+    except where the mixed logits put two labels within eps of each other in score (counted, printed)."""
+    cfg = G.UNET_570M
+    m = paella_amd.Paella(**cfg)
+    weights_for(m, sum(cfg["blocks"]))
+    m = m.to(DEV)
+    B, H = 1, 32
+    L = cfg["num_labels"]
+    c, u = to_dev(cond_for(cfg, B, 0, 0, 2), DEV), to_dev(cond_for(cfg, B, 0, 0, 3), DEV)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randint(0, L, (B, H, H), generator=g).to(DEV)
+    r = torch.full((B,), 0.75, device=DEV)
+    both = {k: (torch.cat([c[k], u[k]]) if c[k] is not None else None) for k in c}
+    cache = m.prepare_cond(**both)
+    a, b = 8.0, -7.0
+    full = m.forward_prepared(torch.cat([x, x]), torch.cat([r, r]), cache).permute(0, 2, 3, 1).contiguous().clone()  # [2B,H,W,L]
+    mixed = m.forward_prepared(x, r, cache, cfg_mix=(a, b)).permute(0, 2, 3, 1).contiguous().clone()                 # [B,H,W,L]
+    ref_mix = full[:B] * a + full[B:] * b
+    diff = (mixed - ref_mix).abs().max().item()
+    rows = B * H * H
+    out_f = torch.empty(B, H, H, dtype=torch.int64, device=DEV)
+    out_u = torch.empty_like(out_f)
+    for temp in (1.0, 0.2):
+        sampling._tail(mixed, None, rows, L, 1.0, 0.0, temp, 0, None, 77, 3, None, None, 0.0, out_f)
+        sampling._tail(full[:B].contiguous(), full[B:].contiguous(), rows, L, a, b, temp, 0, None, 77, 3, None, None, 0.0, out_u)
+        torch.cuda.synchronize()
+        mism = (out_f != out_u).cpu()
+        # decision margin of the unfused path: Gumbel-max score x/T - log q; recompute the two best from the mixed logits + a wide eps
+        n_mis = int(mism.sum())
+        print("benchmarked path vs unfused, T=%.1f: max |logit diff| %.2e, %d / %d tokens differ" % (temp, diff, n_mis, rows))
+        # a flip needs the top-2 Gumbel scores within |diff|/T of each other: bound its frequency instead of an agreement fraction
+        assert n_mis <= 3, "guidance-mix folding changed %d tokens (logit diff %.2e)" % (n_mis, diff)
+    assert diff <= 2e-4 * max(1.0, ref_mix.abs().max().item())
+    am = (mixed.argmax(-1) != ref_mix.argmax(-1))
+    top = ref_mix.topk(2, dim=-1).values
+    near = (top[..., 0] - top[..., 1]) < 1e-3
+    print("argmax agreement of the folded head: %d / %d differ, %d of them at margin < 1e-3" % (int(am.sum()), rows, int((am & near).sum())))
+    assert not (am & ~near).any()
+
+
+def test_tail_row_offset_is_exact(built_lib):
+    """Philox counters are keyed by the GLOBAL row: rows [lo, hi) drawn with row_offset = lo equal the same rows of the full call."""
+    g = torch.Generator().manual_seed(3)
+    rows, L = 96, 256
+    lc = torch.randn(rows, L, generator=g).to(DEV)
+    init = torch.randint(0, L, (rows,), generator=g).to(DEV)
+    full = torch.empty(rows, dtype=torch.int64, device=DEV)
+    sampling._tail(lc, None, rows, L, 1.0, 0.0, 0.7, 0, None, 1234, 5, init, None, 0.4, full)
+    for lo, hi in [(0, 32), (32, 33), (33, 96)]:
+        part = torch.empty(hi - lo, dtype=torch.int64, device=DEV)
+        sampling._tail(lc[lo:hi].contiguous(), None, hi - lo, L, 1.0, 0.0, 0.7, 0, None, 1234, 5, init[lo:hi].contiguous(), None, 0.4, part,
+                       row_offset=lo)
+        assert torch.equal(part, full[lo:hi])
+    wrong = torch.empty(32, dtype=torch.int64, device=DEV)
+    sampling._tail(lc[32:64].contiguous(), None, 32, L, 1.0, 0.0, 0.7, 0, None, 1234, 5, init[32:64].contiguous(), None, 0.4, wrong)
+    assert not torch.equal(wrong, full[32:64])  # without the offset a shard would re-use the noise of rows 0..31
+
+
+def test_philox_shard_equals_unsharded(tiny):
+    """sample(noise="philox", shard=(lo, total)) reproduces rows [lo, lo + B) of the unsharded call bit for bit: start tokens,
+    categorical draws and renoise masks are all functions of (seed, global row, step) -- SURVEY 8e."""
+    cfg = G.UNET_TINY
+    B = 4
+    cs, us = cond_for(cfg, B, 3, 1, 1), cond_for(cfg, B, 3, 1, 2)
+    from paella_amd.dist import shard_bounds, shard_inputs
+    kw = dict(steps=3, renoise_steps=2, device=DEV, noise="philox", seed=99)
+    full = paella_amd.sample(tiny, to_dev(cs, DEV), (B, 16, 16), unconditional_inputs=to_dev(us, DEV), **kw)
+    parts = []
+    for world in (2, 4):
+        parts = []
+        for rank in range(world):
+            lo, hi = shard_bounds(B, rank, world)
+            parts.append(paella_amd.sample(tiny, to_dev(shard_inputs(cs, lo, hi), DEV), (hi - lo, 16, 16),
+                                           unconditional_inputs=to_dev(shard_inputs(us, lo, hi), DEV), shard=(lo, B), **kw))
+        assert torch.equal(full, torch.cat(parts, 0)), "world size %d" % world
+    # seed=None draws a fresh seed per call
+    a = paella_amd.sample(tiny, to_dev(cs, DEV), (B, 16, 16), unconditional_inputs=to_dev(us, DEV), steps=2, renoise_steps=1, device=DEV, noise="philox")
+    b = paella_amd.sample(tiny, to_dev(cs, DEV), (B, 16, 16), unconditional_inputs=to_dev(us, DEV), steps=2, renoise_steps=1, device=DEV, noise="philox")
+    assert not torch.equal(a, b)

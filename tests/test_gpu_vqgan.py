@@ -16,14 +16,21 @@ DEV = "cuda"
 def test_tiny_vs_reference(golden, built_lib, name, vc):
     g = golden(name)
     v = paella_amd.VQModel(**vc)
-    weights_for(v, vc["bottleneck_blocks"], g)
+    sd = weights_for(v, vc["bottleneck_blocks"], g)
     v = v.to(DEV)
     img = torch.from_numpy(g["img"]).to(DEV)
     qe, lat, idx, loss = v.encode(img)
     np.testing.assert_allclose(lat.cpu().numpy(), g["lat"], atol=2e-5)
     mism = idx.cpu().numpy() != g["idx"]
-    print(name, "token mismatches:", int(mism.sum()), "of", mism.size)
-    assert mism.mean() <= 0.01  # nearest-code ties only (unpinned third-party quantiser, see oracle header)
+    # integer output: exact, except where the reference-side latent is equidistant (within eps) from its two nearest codes --
+    # the only place the unpinned third-party quantiser's tie-break / distance formulation can matter.  Counted and printed.
+    rows = (torch.from_numpy(g["lat"]) * vc["scale_factor"]).permute(0, 2, 3, 1).reshape(-1, vc["c_latent"]).double()
+    d = torch.cdist(rows, sd["vquantizer.codebook.weight"].double()).pow(2)
+    top = d.topk(2, dim=1, largest=False).values
+    near = ((top[:, 1] - top[:, 0]) < 1e-5).numpy().reshape(mism.shape)
+    print(name, "token mismatches: %d of %d, all at nearest-code near-ties: %s (%d near-ties present)"
+          % (int(mism.sum()), mism.size, not (mism & ~near).any(), int(near.sum())))
+    assert not (mism & ~near).any(), "%d token(s) differ where the nearest code was unambiguous" % int((mism & ~near).sum())
     if not mism.any():
         np.testing.assert_allclose(qe.cpu().numpy(), g["qe"], atol=1e-6)
         np.testing.assert_allclose(float(loss), float(g["loss"]), rtol=1e-4)

@@ -30,7 +30,10 @@ def test_unet_tiny_forward_and_embeddings(golden):
     np.testing.assert_allclose(out.numpy(), g["logits"], atol=2e-5, rtol=1e-5)
     np.testing.assert_allclose(taps["r_embed"].numpy(), g["r_embed"], atol=1e-6)
     np.testing.assert_allclose(taps["c_embed"].numpy(), g["c_embed"], atol=1e-5)
-    assert (out.argmax(1).numpy() == g["logits"].argmax(1)).mean() > 0.999
+    ref = torch.from_numpy(g["logits"])
+    top = ref.topk(2, dim=1).values
+    mism = out.argmax(1) != ref.argmax(1)
+    assert not (mism & ((top[:, 0] - top[:, 1]) >= 1e-4)).any(), "oracle argmax differs from the reference's away from near-ties"
     # conditioning variants: text-only and CLIP-only (byt5 of length 0)
     c2 = cond_for(cfg, 2, 3, 0, G.COND_SEED + 1)
     with torch.no_grad():
