@@ -131,6 +131,18 @@ int paella_unet_forward_shared(paella_unet* m, const int64_t* tokens, const floa
                                float mix_c, float mix_u, int H, int W, int S, const float* attn_weights,
                                int n_attn_weights, float* logits_out, void* ws, size_t ws_bytes, void* stream);
 
+/* One whole sampling step in the counter-based (Philox) noise mode: Paella.forward followed by the sampling tail
+ * (src/utils.py:43-54) with out_mapper (src/modules.py:184-187) and the tail FUSED: the categorical / argmax decision is taken
+ * on the head GEMM's accumulators, the [rows, num_labels] logits tensor the reference materialises (:44-47) is never written.
+ * Arguments as paella_unet_forward_shared + paella_sample_tail_ex; with a guidance mix (B == 2 * n_unique) tokens_out holds
+ * n_unique x H x W tokens, without one B x H x W (n_unique == B).  Tokens are bit-identical to forward_shared + sample_tail_ex
+ * on the same seed / offset / row_offset. */
+int paella_unet_forward_sample(paella_unet* m, const int64_t* tokens, const float* r, const void* cond, int B, int n_unique,
+                               float mix_c, float mix_u, int H, int W, int S, const float* attn_weights, int n_attn_weights,
+                               float temperature, int mode, uint64_t seed, const uint64_t* seed_ptr, uint64_t offset,
+                               int64_t row_offset, const int64_t* init_noise, float t_next, int64_t* tokens_out, void* ws,
+                               size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Sampling tail and add_noise (reference src/utils.py:45-54; src/modules.py:277-283)
  * ---------------------------------------------------------------------------------------------- */

@@ -56,6 +56,9 @@ SIGNATURES = {
                                     c_void_p, c_void_p, c_size_t, c_void_p]),
     "paella_unet_forward_shared": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_int, c_int, c_int,
                                            c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "paella_unet_forward_sample": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_int, c_int, c_int,
+                                           c_void_p, c_int, c_float, c_int, c_uint64, c_void_p, c_uint64, c_int64, c_void_p, c_float, c_void_p,
+                                           c_void_p, c_size_t, c_void_p]),
     "paella_sample_tail": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, c_float, c_float, c_int, c_void_p,
                                    c_uint64, c_uint64, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
     "paella_sample_tail_ex": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, c_float, c_float, c_int, c_void_p,

@@ -68,6 +68,21 @@ static inline Epilogue make_epilogue() {
     return e;
 }
 
+// Fused sampling tail of the HEAD GEMM (TAIL instantiations of gemm_nt_kernel; reference src/utils.py:47-50 in the counter-based noise
+// mode): instead of storing the [M, N = num_labels] logits, every column tile leaves per row its best (score, label); a tiny second
+// kernel (tail.hip: tail_finalize_kernel) picks the winner across tiles and renoises.  score = logit / T - log q (Gumbel-max, Philox
+// keyed by (seed, global row, label quad, offset)) or the logit itself (mode 1).
+struct FusedTail {
+    float temperature;
+    int mode;                    // 0 categorical, 1 argmax
+    uint64_t seed;
+    const uint64_t* seed_ptr;    // optional device-resident seed word added to seed
+    uint64_t offset;
+    int64_t row_offset;
+    float* part_score;           // [M, tiles_n]
+    int* part_idx;               // [M, tiles_n]
+};
+
 struct GemmArgs {
     const float* A; int lda;   // [M, K] row-major
     const float* W; int ldw;   // [N, K] row-major (torch Linear layout)
@@ -83,12 +98,14 @@ struct GemmArgs {
     int ln_nblk;
     float ln_eps;
     Epilogue ep;
+    FusedTail ft;              // used by launch_gemm_tail only
 };
 
 // Launchers (each returns PAELLA_OK or an error code; all work is enqueued on `stream`).
 // `ws` is a split-K region: kGemmTicketBytes of arrival tickets (zero when first handed to the library -- paella_workspace_init
 // -- and left zero by every launch) followed by slab space for partial tiles; ws_bytes covers both.  ws == nullptr forbids
 // any K split.  One region must not be used by two launches that can run concurrently.
+struct TailArgs;
 static const size_t kGemmMaxTickets = (size_t)1 << 16;                       // one ticket per output tile
 static const size_t kGemmTicketBytes = kGemmMaxTickets * sizeof(unsigned);  // 256 KiB header
 int launch_gemm(const GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t stream);
@@ -96,6 +113,12 @@ int launch_gemm(const GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t stream
 // (classic split-K); splitk < 0: exactly -splitk workgroups (balanced contiguous unit ranges).
 int launch_gemm_cfg(const GemmArgs& g, int cfg, int splitk, void* ws, size_t ws_bytes, hipStream_t stream);
 int gemm_num_tile_configs();
+// Head GEMM with the fused tail epilogue: one whole tile per workgroup; g.ft.part_* are [M, gemm_tail_tiles_n(M, N)].
+int gemm_tail_tiles_n(int M, int N);
+int launch_gemm_tail(const GemmArgs& g, hipStream_t stream);
+// the tile config launch_gemm_tail uses (the unfused head GEMM is launched with the same one: identical logits bit for bit)
+int gemm_tail_config(int M, int N);
+int launch_tail_finalize(const TailArgs& a, const float* part_score, const int* part_idx, int tiles_n, hipStream_t stream);
 // opt-in bf16-operand fast mode (gemm_bf16.hip).  launch_gemm_bf16 returns PAELLA_ERR_STATE when this GEMM has no bf16
 // shadow weight / unsuitable K: the caller falls back to the fp32 kernel.  tile: 0 = 128x128, 1 = 64x64, 2 = 32x32, -1 = choose.
 int launch_gemm_bf16(const GemmArgs& g, int tile, int splitk, void* ws, size_t ws_bytes, hipStream_t stream);

@@ -29,6 +29,7 @@
 //    (same tile / same weight panel) share an XCD's L2.
 #include "common.h"
 #include "gemm_device.h"
+#include "philox.h"
 #include <stdio.h>
 #include <vector>
 
@@ -40,7 +41,7 @@ struct SkPlan {
     unsigned U;            // tiles_m * tiles_n * KT work units
 };
 
-template <int WM, int WN, int TM, int TN, int PD, int APRO>  // APRO: 0 none, 1 GRN scale/shift, 2 LayerNorm from row statistics
+template <int WM, int WN, int TM, int TN, int PD, int APRO, bool TAIL = false>  // APRO: 0 none, 1 GRN scale/shift, 2 LayerNorm from row statistics; TAIL: fused sampling tail (head GEMM)
 __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs g, SkPlan p, float* __restrict__ slabs,
                                                                unsigned* __restrict__ tickets, unsigned slab_bytes) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16, BK = 32;
@@ -52,7 +53,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs g, SkPla
     static_assert(PD == 1 || PD == 2, "prefetch ring depth 1 or 2");
     // one LDS object: two tile stages + 16 floats for the ticket broadcast (the NEXT unit's tile is already staged when a
     // segment is flushed, so the flag cannot live inside the stages)
-    __shared__ __attribute__((aligned(16))) float smem[2 * TILE_FLOATS + 16];
+    constexpr int TAIL_FLOATS = TAIL ? BM * WN * 2 : 0;  // fused tail: per row and wave column, the best (score, label)
+    __shared__ __attribute__((aligned(16))) float smem[2 * TILE_FLOATS + 16 + TAIL_FLOATS];
 
     // ---- this workgroup's unit range ----
     const unsigned G = gridDim.x;
@@ -238,6 +240,58 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs g, SkPla
 
     // ---- epilogue of a finished tile: lane holds out[m = ..+r16][n = ..+kq*4 .. +3] ----
     auto epilogue = [&](int m0, int n0, int r16, int kq) {
+        if constexpr (TAIL) {
+            // ---- fused sampling tail: logits never leave the registers ----
+#pragma clang fp contract(off)
+            const FusedTail& ft = g.ft;
+            const uint64_t seed = ft.seed + (ft.seed_ptr ? *ft.seed_ptr : 0ull);
+            const int L4 = g.N >> 2;
+            float* s_score = smem + 2 * TILE_FLOATS + 16;
+            int* s_idx = reinterpret_cast<int*>(s_score + BM * WN);
+            const int tile_n_id = n0 / BN;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int mrow = (wm * TM + i) * 16 + r16;  // row inside the tile
+                const int m = m0 + mrow;
+                float best = -INFINITY;
+                int best_i = 0x7fffffff;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int nn = n0 + (wn * TN + j) * 16 + kq * 4;
+                    if (m < g.M && nn < g.N) {
+                        const f32x4 v = epilogue_apply(g.ep, g.N, m, nn, acc[i][j]);
+                        if (ft.mode == 1) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) argmax_update(best, best_i, v[e], nn + e);
+                        } else {
+                            uint32_t rb[4];
+                            philox4x32(seed, (uint64_t)(m + ft.row_offset) * L4 + (nn >> 2), ft.offset, rb);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) argmax_update(best, best_i, tail_score_gumbel(v[e], ft.temperature, log_exp1(rb[e])), nn + e);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int o = 16; o < 64; o <<= 1) {  // the 4 lanes (kq = 0..3) that share row r16
+                    const float ov = __shfl_xor(best, o, 64);
+                    const int oi = __shfl_xor(best_i, o, 64);
+                    argmax_update(best, best_i, ov, oi);
+                }
+                if (kq == 0) { s_score[mrow * WN + wn] = best; s_idx[mrow * WN + wn] = best_i; }
+            }
+            __syncthreads();
+            if (tid < BM && m0 + tid < g.M) {
+                float best = s_score[tid * WN];
+                int best_i = s_idx[tid * WN];
+#pragma unroll
+                for (int w = 1; w < WN; ++w) argmax_update(best, best_i, s_score[tid * WN + w], s_idx[tid * WN + w]);
+                const size_t o = (size_t)(m0 + tid) * p.tiles_n + tile_n_id;
+                ft.part_score[o] = best;
+                ft.part_idx[o] = best_i;
+            }
+            __syncthreads();  // the scratch is reused by this workgroup's next tile
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int m = m0 + (wm * TM + i) * 16 + r16;
@@ -450,36 +504,41 @@ static inline long tiles_of_cfg(int c, int M, int N) {
     return (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
 }
 
-// Tile / workgroup-count choice, fitted to tools/gemm_tune.py sweeps on MI355X (profiles/r02_gemm_tile_sweep*.txt).
-// Returns the tile config and G (number of workgroups = number of contiguous unit ranges).
+// Tile / workgroup-count choice, fitted to tools/gemm_tune.py sweeps on MI355X (profiles/r02_gemm_tile_sweep.txt).
+// Returns the tile config and G (number of workgroups = number of contiguous unit ranges).  What the sweeps show:
+//  * >= 1024 tiles of 128x128: one tile per workgroup, 8 waves (cfg 10): 127-133 TFLOP/s at any K;
+//  * fewer tiles but >= 5 GFLOP: the same tile with G = 512 balanced ranges (2 workgroups per CU; every CU busy whatever the tile
+//    count: 1024x1280x5120 runs 125 us where one-tile-per-workgroup 64x64 tiles took 150);
+//  * 2.4-5 GFLOP: 128x64 tiles, 8 waves, one workgroup per CU (G = 256);
+//  * many small tiles with a short K (VQGAN full-resolution levels): 64x64 tiles, one each;
+//  * skinny batch-1 shapes: 32x32 tiles (5 workgroups per CU), ~10 K-steps per workgroup, at most 1280 workgroups -- every larger
+//    tile lands within 5 % of it (24-27 us for 128x5120x1280): these launches are bound by ramp + combine, not by the tile.
 static void choose_config(int M, int N, int K, size_t slab_cap_bytes, int* cfg_out, unsigned* G_out) {
-    const int ktiles = (K + 31) / 32;
+    const long ktiles = (K + 31) / 32;
     const double macs = (double)M * N * K;
+    const long T128 = tiles_of_cfg(10, M, N), T64 = tiles_of_cfg(18, M, N), T32 = tiles_of_cfg(5, M, N);
     int cfg;
-    long S = 1;
-    if (tiles_of_cfg(0, M, N) >= 1024) {  // >= 4 workgroups of 128x128 per CU: the big tile with 8 waves (32x64 wave tiles) wins at any K
-        cfg = 9;
-    } else if (tiles_of_cfg(2, M, N) >= 1024 || macs >= 3e9) {  // big problems: 64x64 tiles, split only to reach ~1024 workgroups
-        cfg = 2;
-        const long t = tiles_of_cfg(2, M, N);
-        while (t * S < 1024 && S < 16 && ktiles / (S * 2) >= 5) S *= 2;
-    } else {                                                     // skinny: 32x32 tiles, K loop <= 20 tiles, >= 512 workgroups
+    long G;
+    if (T128 >= 1024) { cfg = 10; G = T128; }
+    else if (macs >= 2.5e9) { cfg = 10; G = T128 * ktiles >= 512 * 3 ? 512 : T128; }
+    else if (macs >= 1.2e9) { cfg = 14; G = 256; }
+    else if (T64 >= 1024) { cfg = 18; G = T64; }
+    else {
         cfg = 5;
-        const long t = tiles_of_cfg(5, M, N);
-        if (t < 1024) {
-            while (ktiles / S > 20 && S < 16) S *= 2;
-            while (t * S < (t >= 512 ? 1024 : 512) && S < 16 && ktiles / (S * 2) >= 5) S *= 2;
-            while (S > 1 && t * S > 2560) S /= 2;
-        }
+        const long U = T32 * ktiles;
+        G = U / 10;
+        if (G < T32) G = T32;
+        if (G > 1280) G = 1280;
     }
-    long G = tiles_of_cfg(cfg, M, N) * S;
-    const long U = tiles_of_cfg(cfg, M, N) * ktiles;
+    const long T = tiles_of_cfg(cfg, M, N);
+    const long U = T * ktiles;
     if (G > U) G = U;
+    if (G < 1) G = 1;
     // workspace limits: partial tiles need 2 slab slots per workgroup and one ticket per tile
     const int BM = kCfgs[cfg].wm * kCfgs[cfg].tm * 16, BN = kCfgs[cfg].wn * kCfgs[cfg].tn * 16;
-    if (G != tiles_of_cfg(cfg, M, N)) {
+    if (G != T) {
         const size_t slot = (size_t)BM * BN * sizeof(float);
-        if (tiles_of_cfg(cfg, M, N) > (long)kGemmMaxTickets || slot * 2 > slab_cap_bytes) G = tiles_of_cfg(cfg, M, N);
+        if (T > (long)kGemmMaxTickets || slot * 2 > slab_cap_bytes) G = T;
         else if ((size_t)G * 2 * slot > slab_cap_bytes) G = (long)(slab_cap_bytes / (2 * slot));
     }
     *cfg_out = cfg;
@@ -638,6 +697,37 @@ static int launch_gemm_cfg_impl(const GemmArgs& g, int cfg, int splitk, void* ws
         default: paella_set_error("gemm: bad tile config %d", cfg); return PAELLA_ERR_ARG;
     }
 #undef GEMM_CASE
+    LAUNCH_CHECK_RET();
+    return PAELLA_OK;
+}
+
+// ---------------------------------------------------------------------------
+// head GEMM with the fused sampling tail: one whole tile per workgroup (G = tiles), TAIL instantiations only
+// ---------------------------------------------------------------------------
+int gemm_tail_config(int M, int N) { return tiles_of_cfg(9, M, N) >= 256 ? 9 : 2; }
+int gemm_tail_tiles_n(int M, int N) {
+    const TileCfg& tc = kCfgs[gemm_tail_config(M, N)];
+    const int BN = tc.wn * tc.tn * 16;
+    return (N + BN - 1) / BN;
+}
+int launch_gemm_tail(const GemmArgs& g, hipStream_t st) {
+    if (g.M <= 0 || g.N <= 0) return PAELLA_OK;
+    if ((g.K & 3) || (g.N & 3) || (g.lda & 3) || (g.ldw & 3) || g.a_scale || g.ln_stats || !g.ft.part_score || !g.ft.part_idx) {
+        paella_set_error("gemm_tail: unsupported arguments (M=%d N=%d K=%d)", g.M, g.N, g.K);
+        return PAELLA_ERR_ARG;
+    }
+    const int cfg = gemm_tail_config(g.M, g.N);
+    const TileCfg& tc = kCfgs[cfg];
+    const int BM = tc.wm * tc.tm * 16, BN = tc.wn * tc.tn * 16;
+    SkPlan p;
+    p.tiles_m = (g.M + BM - 1) / BM;
+    p.tiles_n = (g.N + BN - 1) / BN;
+    p.KT = (g.K + 31) / 32;
+    const unsigned long long T = (unsigned long long)p.tiles_m * p.tiles_n;
+    if (T * (unsigned long long)p.KT >= (1ull << 31)) { paella_set_error("gemm_tail: problem too large"); return PAELLA_ERR_ARG; }
+    p.U = (unsigned)(T * p.KT);
+    if (cfg == 9) hipLaunchKernelGGL((gemm_nt_kernel<4, 2, 2, 4, 1, 0, true>), dim3((unsigned)T), dim3(512), 0, st, g, p, (float*)nullptr, (unsigned*)nullptr, 0u);
+    else hipLaunchKernelGGL((gemm_nt_kernel<2, 2, 2, 2, 2, 0, true>), dim3((unsigned)T), dim3(256), 0, st, g, p, (float*)nullptr, (unsigned*)nullptr, 0u);
     LAUNCH_CHECK_RET();
     return PAELLA_OK;
 }

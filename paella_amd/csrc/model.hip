@@ -644,11 +644,13 @@ extern "C" int paella_unet_forward(paella_unet* m, const int64_t* tokens, const 
 // The guidance mix l = mix_c * l_cond + mix_u * l_uncond (src/utils.py:47) can ride through the bias-free linear head
 // (out_mapper, src/modules.py:184-187): with (mix_c, mix_u) != (0, 0) and B == 2 * n_unique the head runs once on
 // mix_c * LN(z_cond) + mix_u * LN(z_uncond) and logits_out receives the n_unique MIXED rows (half the head FLOPs and logits bytes).
-extern "C" int paella_unet_forward_shared(paella_unet* m, const int64_t* tokens, const float* r, const void* cond, int B, int n_unique,
-                                          float mix_c, float mix_u, int H, int W, int S, const float* attn_weights,
-                                          int n_attn_weights, float* logits_out, void* ws, size_t ws_bytes, void* stream) {
+// `tail` != nullptr: the head GEMM runs with the fused sampling-tail epilogue (no logits are stored; tail->tokens_out receives
+// the sampled tokens of the B (or, with the guidance mix, n_unique) output rows); logits_out is then unused.
+static int unet_forward_impl(paella_unet* m, const int64_t* tokens, const float* r, const void* cond, int B, int n_unique,
+                             float mix_c, float mix_u, int H, int W, int S, const float* attn_weights,
+                             int n_attn_weights, float* logits_out, const TailArgs* tail, void* ws, size_t ws_bytes, void* stream) {
     if (!m || !m->finalized) { paella_set_error("model not finalized"); return PAELLA_ERR_STATE; }
-    if (!tokens || !r || !logits_out) { paella_set_error("null argument"); return PAELLA_ERR_ARG; }
+    if (!tokens || !r || (!logits_out && !tail)) { paella_set_error("null argument"); return PAELLA_ERR_ARG; }
     const paella_unet_config& c = m->cfg;
     const int p = c.patch_size;
     const int div = p << (c.n_levels - 1);
@@ -778,9 +780,56 @@ extern "C" int paella_unet_forward_shared(paella_unet* m, const int64_t* tokens,
             RET_IF(launch_axpby(f.h, f.h + (size_t)nt * c.c_out, mix_c, mix_u, nt * c.c_out, st));
         }
         GemmArgs go = gemm_args(f.h, c.c_out, T(m, "out_mapper.1.weight"), c.c_out, logits_out, c.num_labels, (int)nt, c.num_labels, c.c_out);
-        RET_IF(launch_gemm(go, f.splitk, kSplitKBudget, st));
+        if (!tail) {
+            // same tile config as the fused-tail launch below (one whole tile per workgroup, no K split): the two paths produce
+            // bit-identical logits, hence identical tokens
+            RET_IF(launch_gemm_cfg(go, gemm_tail_config((int)nt, c.num_labels), 1, f.splitk, kSplitKBudget, st));
+        } else {
+            // out_mapper fused with the sampling tail (reference src/utils.py:44-50 materialises the logits; here they never leave
+            // the registers): per row and column tile the best (score, label) lands in f.g (free after the LayerNorm above)
+            const int tn = gemm_tail_tiles_n((int)nt, c.num_labels);
+            if ((size_t)tn * 2 > (size_t)c.c_out) { paella_set_error("fused tail: partial buffer does not fit (tiles_n=%d, c_out=%d)", tn, c.c_out); return PAELLA_ERR_ARG; }
+            if (tail->rows != nt || tail->L != c.num_labels) { paella_set_error("fused tail: row / label count mismatch"); return PAELLA_ERR_ARG; }
+            go.C = nullptr;
+            go.ft.temperature = tail->temperature; go.ft.mode = tail->mode; go.ft.seed = tail->seed; go.ft.seed_ptr = tail->seed_ptr;
+            go.ft.offset = tail->offset; go.ft.row_offset = tail->row_offset;
+            go.ft.part_score = f.g;
+            go.ft.part_idx = reinterpret_cast<int*>(f.g + (size_t)nt * tn);
+            RET_IF(launch_gemm_tail(go, st));
+            RET_IF(launch_tail_finalize(*tail, go.ft.part_score, go.ft.part_idx, tn, st));
+        }
     }
     return PAELLA_OK;
+}
+
+extern "C" int paella_unet_forward_shared(paella_unet* m, const int64_t* tokens, const float* r, const void* cond, int B, int n_unique,
+                                          float mix_c, float mix_u, int H, int W, int S, const float* attn_weights,
+                                          int n_attn_weights, float* logits_out, void* ws, size_t ws_bytes, void* stream) {
+    if (!logits_out) { paella_set_error("null argument"); return PAELLA_ERR_ARG; }
+    return unet_forward_impl(m, tokens, r, cond, B, n_unique, mix_c, mix_u, H, W, S, attn_weights, n_attn_weights, logits_out, nullptr, ws, ws_bytes, stream);
+}
+
+// One whole sampling step for the counter-based noise mode: Paella.forward + the sampling tail (src/utils.py:43-54) with the head
+// GEMM and the tail fused -- the [rows, num_labels] logits are never written.  Output rows: n_unique with the guidance mix
+// (B == 2 * n_unique, (mix_c, mix_u) != (0, 0)), otherwise B (no guidance; n_unique must equal B).
+extern "C" int paella_unet_forward_sample(paella_unet* m, const int64_t* tokens, const float* r, const void* cond, int B, int n_unique,
+                                          float mix_c, float mix_u, int H, int W, int S, const float* attn_weights, int n_attn_weights,
+                                          float temperature, int mode, uint64_t seed, const uint64_t* seed_ptr, uint64_t offset,
+                                          int64_t row_offset, const int64_t* init_noise, float t_next, int64_t* tokens_out,
+                                          void* ws, size_t ws_bytes, void* stream) {
+    if (!tokens_out) { paella_set_error("null argument"); return PAELLA_ERR_ARG; }
+    const bool mix = mix_c != 0.f || mix_u != 0.f;
+    if (!mix && n_unique != B) { paella_set_error("forward_sample without a guidance mix needs n_unique == B (separate cond / uncond logits take the unfused path)"); return PAELLA_ERR_ARG; }
+    if (mode == 0 && !(temperature > 0.f)) { paella_set_error("temperature must be > 0 in categorical mode (use mode=1 for argmax)"); return PAELLA_ERR_ARG; }
+    if (row_offset < 0) { paella_set_error("row_offset must be >= 0"); return PAELLA_ERR_ARG; }
+    TailArgs a;
+    a.logits_c = nullptr; a.logits_u = nullptr;
+    a.rows = (int64_t)(mix ? n_unique : B) * H * W;
+    a.L = m ? m->cfg.num_labels : 0;
+    a.cfg = 1.f; a.one_minus_cfg = 0.f; a.temperature = temperature; a.mode = mode; a.noise_q = nullptr; a.seed = seed; a.seed_ptr = seed_ptr;
+    a.offset = offset; a.row_offset = row_offset; a.init_noise = init_noise; a.mask_u = nullptr; a.t_next = t_next;
+    a.tokens_out = tokens_out; a.sampled_out = nullptr;
+    return unet_forward_impl(m, tokens, r, cond, B, n_unique, mix_c, mix_u, H, W, S, attn_weights, n_attn_weights, nullptr, &a, ws, ws_bytes, stream);
 }
 
 // ---------------------------------------------------------------------------

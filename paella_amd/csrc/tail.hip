@@ -12,37 +12,29 @@
 // Noise comes either from caller-provided tensors (parity mode: bit-identical draws to torch given the
 // same q / u) or from an in-kernel Philox4x32-10 stream keyed by (seed, offset).
 #include "common.h"
+#include "philox.h"
 #include <math.h>
 
 #pragma clang fp contract(off)
 
-__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
-    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
-    const uint32_t n1 = (uint32_t)p1;
-    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
-    const uint32_t n3 = (uint32_t)p0;
-    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-}
-__device__ __forceinline__ void philox4x32(uint64_t seed, uint64_t ctr_lo, uint64_t ctr_hi, uint32_t (&out)[4]) {
-    uint32_t c[4] = {(uint32_t)ctr_lo, (uint32_t)(ctr_lo >> 32), (uint32_t)ctr_hi, (uint32_t)(ctr_hi >> 32)};
-    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-    for (int i = 0; i < 10; ++i) {
-        philox_round(c, k0, k1);
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-    out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
-}
-// (0,1): 24 random bits, never 0 -> -log(u) finite and > 0
-__device__ __forceinline__ float u01_open(uint32_t bits) { return ((float)(bits >> 8) + 0.5f) * (1.0f / 16777216.0f); }
-// [0,1): torch.rand semantics (24-bit mantissa grid)
-__device__ __forceinline__ float u01_half_open(uint32_t bits) { return (float)(bits >> 8) * (1.0f / 16777216.0f); }
-
 __device__ __forceinline__ float mix_logit(float lc, float lu, float cfg, float omc, bool has_u) {
     return has_u ? __fadd_rn(__fmul_rn(lc, cfg), __fmul_rn(lu, omc)) : lc;
+}
+
+// renoise (src/utils.py:54 -> src/modules.py:277-283 with random_x = init_noise): u <= t_next ? init_noise : token
+__device__ __forceinline__ int64_t renoise_token(const TailArgs& a, uint64_t seed, int64_t row, int64_t tok) {
+    if (a.init_noise) {
+        float u;
+        if (a.mask_u) {
+            u = a.mask_u[row];
+        } else {
+            uint32_t rb[4];
+            philox4x32(seed ^ 0x5bd1e9955bd1e995ull, (uint64_t)(row + a.row_offset), a.offset, rb);
+            u = u01_half_open(rb[0]);
+        }
+        if (u <= a.t_next) tok = a.init_noise[row];
+    }
+    return tok;
 }
 
 __global__ __launch_bounds__(256) void sample_tail_kernel(TailArgs a) {
@@ -56,30 +48,30 @@ __global__ __launch_bounds__(256) void sample_tail_kernel(TailArgs a) {
     const bool has_u = lu != nullptr;
     const bool argmax_mode = a.mode == 1;
     const uint64_t seed = a.seed + (a.seed_ptr ? *a.seed_ptr : 0ull);
+    const float* nq = a.noise_q ? a.noise_q + row * L : nullptr;
 
-    // pass 1: max of x = mix / T
-    float mx = -INFINITY;
-    for (int i4 = tid; i4 < L4; i4 += 256) {
-        const f32x4 c = *reinterpret_cast<const f32x4*>(lc + i4 * 4);
-        const f32x4 u = has_u ? *reinterpret_cast<const f32x4*>(lu + i4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    // pass 1 (explicit-noise parity mode only): max of x = mix / T for the softmax numerator exp(x - max).
+    // The argmax and the counter-based mode never need it: argmax(x - log q) is invariant to a per-row shift.
+    float mx = 0.f;
+    if (nq && !argmax_mode) {
+        mx = -INFINITY;
+        for (int i4 = tid; i4 < L4; i4 += 256) {
+            const f32x4 c = *reinterpret_cast<const f32x4*>(lc + i4 * 4);
+            const f32x4 u = has_u ? *reinterpret_cast<const f32x4*>(lu + i4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float x = mix_logit(c[e], u[e], a.cfg, a.one_minus_cfg, has_u);
-            if (!argmax_mode) x = __fdiv_rn(x, a.temperature);
-            mx = fmaxf(mx, x);
+            for (int e = 0; e < 4; ++e) mx = fmaxf(mx, __fdiv_rn(mix_logit(c[e], u[e], a.cfg, a.one_minus_cfg, has_u), a.temperature));
         }
-    }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-    if (lane == 0) red_v[wave] = mx;
-    __syncthreads();
-    mx = fmaxf(fmaxf(red_v[0], red_v[1]), fmaxf(red_v[2], red_v[3]));
-    __syncthreads();
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        if (lane == 0) red_v[wave] = mx;
+        __syncthreads();
+        mx = fmaxf(fmaxf(red_v[0], red_v[1]), fmaxf(red_v[2], red_v[3]));
+        __syncthreads();
+    }
 
     // pass 2: best score (first index wins ties)
     float best = -INFINITY;
     int best_i = 0x7fffffff;
-    const float* nq = a.noise_q ? a.noise_q + row * L : nullptr;
     for (int i4 = tid; i4 < L4; i4 += 256) {
         const f32x4 c = *reinterpret_cast<const f32x4*>(lc + i4 * 4);
         const f32x4 u = has_u ? *reinterpret_cast<const f32x4*>(lu + i4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -91,7 +83,7 @@ __global__ __launch_bounds__(256) void sample_tail_kernel(TailArgs a) {
                 uint32_t rb[4];
                 philox4x32(seed, (uint64_t)(row + a.row_offset) * L4 + i4, a.offset, rb);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) q[e] = __logf(-logf(u01_open(rb[e])));  // log of an Exp(1) variate: argmax(p/q) == argmax(log p - log q)
+                for (int e = 0; e < 4; ++e) q[e] = log_exp1(rb[e]);
             }
         }
 #pragma unroll
@@ -103,41 +95,53 @@ __global__ __launch_bounds__(256) void sample_tail_kernel(TailArgs a) {
             } else if (nq) {  // parity mode: the reference's arithmetic, softmax numerator over Exp(1) noise
                 x = __fdiv_rn(x, a.temperature);
                 score = __fdiv_rn(expf(__fsub_rn(x, mx)), q[e]);
-            } else {          // counter-based noise: the same draw in the log domain (Gumbel-max), no exp and no second division
-                x = __fdiv_rn(x, a.temperature);
-                score = (x - mx) - q[e];
+            } else {          // counter-based noise: the same draw in the log domain (Gumbel-max); identical arithmetic in the
+                score = tail_score_gumbel(x, a.temperature, q[e]);  // head GEMM's fused tail epilogue (gemm.hip)
             }
-            const int idx = i4 * 4 + e;
-            if (score > best || (score == best && idx < best_i)) { best = score; best_i = idx; }
+            argmax_update(best, best_i, score, i4 * 4 + e);
         }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const float ov = __shfl_xor(best, o, 64);
         const int oi = __shfl_xor(best_i, o, 64);
-        if (ov > best || (ov == best && oi < best_i)) { best = ov; best_i = oi; }
+        argmax_update(best, best_i, ov, oi);
     }
     if (lane == 0) { red_v[wave] = best; red_i[wave] = best_i; }
     __syncthreads();
     if (tid == 0) {
-        for (int w = 1; w < 4; ++w)
-            if (red_v[w] > best || (red_v[w] == best && red_i[w] < best_i)) { best = red_v[w]; best_i = red_i[w]; }
+        for (int w = 1; w < 4; ++w) argmax_update(best, best_i, red_v[w], red_i[w]);
         if (best_i == 0x7fffffff) best_i = 0;  // all-NaN row
         int64_t tok = best_i;
         if (a.sampled_out) a.sampled_out[row] = tok;
-        if (a.init_noise) {
-            float u;
-            if (a.mask_u) {
-                u = a.mask_u[row];
-            } else {
-                uint32_t rb[4];
-                philox4x32(seed ^ 0x5bd1e9955bd1e995ull, (uint64_t)(row + a.row_offset), a.offset, rb);
-                u = u01_half_open(rb[0]);
-            }
-            if (u <= a.t_next) tok = a.init_noise[row];
-        }
-        a.tokens_out[row] = tok;
+        a.tokens_out[row] = renoise_token(a, seed, row, tok);
     }
+}
+
+// Second half of the FUSED tail: the head GEMM's epilogue (gemm.hip, TAIL instantiations) left, per row and column tile, the best
+// (score, label) of that tile; pick the row's winner in tile order (first index wins ties -> identical to the one-kernel tail),
+// renoise, store the token.  One thread per row.
+__global__ __launch_bounds__(256) void tail_finalize_kernel(TailArgs a, const float* __restrict__ part_score, const int* __restrict__ part_idx,
+                                                            int tiles_n) {
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= a.rows) return;
+    const uint64_t seed = a.seed + (a.seed_ptr ? *a.seed_ptr : 0ull);
+    float best = -INFINITY;
+    int best_i = 0x7fffffff;
+    const float* ps = part_score + row * tiles_n;
+    const int* pi = part_idx + row * tiles_n;
+    for (int t = 0; t < tiles_n; ++t) argmax_update(best, best_i, ps[t], pi[t]);
+    if (best_i == 0x7fffffff) best_i = 0;
+    int64_t tok = best_i;
+    if (a.sampled_out) a.sampled_out[row] = tok;
+    a.tokens_out[row] = renoise_token(a, seed, row, tok);
+}
+
+int launch_tail_finalize(const TailArgs& a, const float* part_score, const int* part_idx, int tiles_n, hipStream_t st) {
+    if (a.rows <= 0) return PAELLA_OK;
+    hipLaunchKernelGGL(tail_finalize_kernel, dim3((unsigned)((a.rows + 255) / 256)), dim3(256), 0, st, a, part_score, part_idx, tiles_n);
+    LAUNCH_CHECK_RET();
+    return PAELLA_OK;
 }
 
 int launch_sample_tail(const TailArgs& a, hipStream_t st) {

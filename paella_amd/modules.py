@@ -357,6 +357,36 @@ class Paella(nn.Module):
                                                       _lib.stream_ptr(dev)))
         return out.permute(0, 3, 1, 2)
 
+    def forward_sample(self, x, r, cond, out, *, temperature, argmax=False, seed=0, seed_dev=None, offset=0, row_offset=0,
+                       init_noise=None, t_next=0.0, cfg_mix=None, attn_weights=None, ws=None):
+        """One whole sampling step in the counter-based noise mode (src/utils.py:43-54): the denoiser evaluation with the head
+        GEMM and the sampling tail FUSED -- the [B, num_labels, H, W] logits are never materialised.  x int64 [Bx,H,W], r [Bx];
+        cfg_mix=(a, b) with cond.B == 2*Bx folds classifier-free guidance through the head (as forward_prepared); without it
+        cond.B must equal Bx.  `out` int64 [Bx,H,W] receives the tokens (renoised against init_noise with u <= t_next when
+        init_noise is given).  Bit-identical to forward_prepared + the tail kernel on the same seed."""
+        h = self._engine()
+        lib = _lib.load()
+        dev = self._device()
+        if not x.is_cuda or x.dtype != torch.int64 or x.dim() != 3:
+            raise ValueError("x must be an int64 HIP tensor [B, H, W]")
+        x = x.contiguous()
+        nu, H, W = x.shape
+        r = self._f32(r, "r")
+        B = cond.B
+        mix = (0.0, 0.0) if cfg_mix is None else (float(cfg_mix[0]), float(cfg_mix[1]))
+        if (cfg_mix is None and B != nu) or (cfg_mix is not None and (B != 2 * nu or mix == (0.0, 0.0))):
+            raise ValueError("forward_sample needs cond.B == Bx (no guidance) or cond.B == 2*Bx with a non-zero cfg_mix")
+        if tuple(out.shape) != (nu, H, W) or out.dtype != torch.int64 or not out.is_contiguous():
+            raise ValueError("out must be a contiguous int64 [B,H,W] tensor")
+        aw = self._f32(attn_weights, "attn_weights")
+        with torch.cuda.device(dev):
+            ws = self._workspace(lib.paella_unet_workspace_bytes(h, B, H, W, cond.S), ws)
+            _lib.check(lib.paella_unet_forward_sample(h, _lib.ptr(x), _lib.ptr(r), _lib.ptr(cond.buf), B, nu, mix[0], mix[1], H, W, cond.S,
+                                                      _lib.ptr(aw), 0 if aw is None else aw.numel(), float(temperature), 1 if argmax else 0,
+                                                      int(seed), _lib.ptr(seed_dev), int(offset), int(row_offset), _lib.ptr(init_noise),
+                                                      float(t_next), _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)))
+        return out
+
     def forward(self, x, r, byt5, clip=None, clip_image=None, x_cat=None, **kwargs):
         """reference src/modules.py:263-275 (kwargs -> attn_weights as utils/modules.py:268). Inference only."""
         if x_cat is not None:

@@ -108,7 +108,7 @@ def timestep_table(t_list, steps, B, device):
 
 def _sample_core(model, model_inputs, unconditional_inputs, latent_shape, init_x, steps, renoise_steps, t_list, temperatures,
                  cfgs, device, noise="torch", seed=None, attn_weights=None, seed_dev=None, init_noise_buf=None, r_all=None, shard=None,
-                 ws=None):
+                 ws=None, fused_tail=True):
     """cfgs: per-step list of (cfg_fp32, one_minus_cfg_fp32) or None (no guidance at that step).
     seed_dev / init_noise_buf / r_all: device-resident seed word, pre-drawn start tokens and the [steps, B] timestep table
     (HIP-graph capture cannot upload from the host, see GraphSampler); ws: caller-owned workspace for every library call.
@@ -149,39 +149,53 @@ def _sample_core(model, model_inputs, unconditional_inputs, latent_shape, init_x
             if any_cfg and _same_cond_layout(model_inputs, unconditional_inputs):
                 cond_both = model.prepare_cond(**_cat_inputs(model_inputs, unconditional_inputs), ws=ws)
                 batched = True
-                logits2 = torch.empty(2 * B, H, W, L, dtype=torch.float32, device=device)
             if not batched or not all(c is not None for c in cfgs):
                 cond_c = model.prepare_cond(**model_inputs, ws=ws)
                 cond_u = model.prepare_cond(**unconditional_inputs, ws=ws) if any_cfg and not batched else None
-            logits_c = torch.empty(B, H, W, L, dtype=torch.float32, device=device)
-            logits_u = torch.empty(B, H, W, L, dtype=torch.float32, device=device) if any_cfg and not batched else None
+        # logits buffers exist only for steps that take the unfused path (allocated on first use: 8.6 GB each at BASELINE configs[2])
+        bufs = {}
+        def logits_buf(name, rows_b):
+            if name not in bufs:
+                bufs[name] = torch.empty(rows_b, H, W, L, dtype=torch.float32, device=device)
+            return bufs[name]
         out = torch.empty(B, H, W, dtype=torch.int64, device=device)
         if r_all is None:
             r_all = timestep_table(t_list, steps, B, device)
+        fuse = philox and native and fused_tail  # head GEMM + tail in one launch: no logits tensor at all
         for i in range(steps):
             r = r_all[i]
             use_cfg = cfgs[i] is not None
+            temp = temperatures[i]
+            mode = 1 if temp == 0 else 0
+            renoise = i < renoise_steps
+            if fuse and ((use_cfg and batched and mode == 0) or not use_cfg):
+                # in place is safe: the token gather at the head of the forward and the token store at its tail are different kernels
+                # of one stream
+                model.forward_sample(sampled, r, cond_both if use_cfg else cond_c, out, temperature=temp if mode == 0 else 1.0, argmax=mode == 1,
+                                     seed=seed, seed_dev=seed_dev, offset=i, row_offset=row_offset, init_noise=init_noise if renoise else None,
+                                     t_next=t_list[i + 1] if renoise else 0.0, cfg_mix=cfgs[i] if use_cfg else None, attn_weights=attn_weights, ws=ws)
+                sampled = out
+                continue
             if native:
                 if use_cfg and batched:
                     # one evaluation against the 2B-row conditioning cache: tokens / r are passed once, the library computes
                     # the conditioning-free prefix for them and replicates it where the two passes diverge.  With the
                     # counter-based generator (no bit-parity promise towards torch's RNG stream) a categorical step also lets
                     # the guidance mix ride through the linear head: one mixed logits tensor comes back.
-                    fold = philox and temperatures[i] != 0
+                    fold = philox and mode == 0
+                    logits2 = logits_buf("both", 2 * B)
                     model.forward_prepared(sampled, r, cond_both, attn_weights=attn_weights, out=logits2[:B] if fold else logits2,
                                            cfg_mix=cfgs[i] if fold else None, ws=ws)
                     lc, lu = logits2[:B], (None if fold else logits2[B:])
                 else:
-                    model.forward_prepared(sampled, r, cond_c, attn_weights=attn_weights, out=logits_c, ws=ws)
-                    lc, lu = logits_c, None
+                    lc, lu = logits_buf("c", B), None
+                    model.forward_prepared(sampled, r, cond_c, attn_weights=attn_weights, out=lc, ws=ws)
                     if use_cfg:
-                        model.forward_prepared(sampled, r, cond_u, attn_weights=attn_weights, out=logits_u, ws=ws)
-                        lu = logits_u
+                        lu = logits_buf("u", B)
+                        model.forward_prepared(sampled, r, cond_u, attn_weights=attn_weights, out=lu, ws=ws)
             else:  # any other callable with the reference's signature; logits come back [B, L, H, W]
                 lc = model(sampled, r, **model_inputs).permute(0, 2, 3, 1).float().contiguous()
                 lu = model(sampled, r, **unconditional_inputs).permute(0, 2, 3, 1).float().contiguous() if use_cfg else None
-            temp = temperatures[i]
-            mode = 1 if temp == 0 else 0
             noise_q = None
             if explicit and mode == 0:
                 noise_q = noise["q"][i].to(device=device, dtype=torch.float32).contiguous()
@@ -193,7 +207,6 @@ def _sample_core(model, model_inputs, unconditional_inputs, latent_shape, init_x
                     noise_q = torch.empty(L, rows, dtype=torch.float32, device=device).exponential_(1).t().contiguous()
                 else:
                     noise_q = torch.empty(rows, L, dtype=torch.float32, device=device).exponential_(1)
-            renoise = i < renoise_steps
             mask_u = None
             if renoise and explicit:
                 mask_u = noise["u"][i].to(device=device, dtype=torch.float32).contiguous()
@@ -208,11 +221,13 @@ def _sample_core(model, model_inputs, unconditional_inputs, latent_shape, init_x
 
 
 def sample(model, model_inputs, latent_shape, unconditional_inputs=None, steps=12, renoise_steps=11, temperature=(1.0, 0.2),
-           cfg=8.0, t_start=1.0, t_end=0.0, device="cuda", *, noise="torch", seed=None, attn_weights=None, shard=None):
+           cfg=8.0, t_start=1.0, t_end=0.0, device="cuda", *, noise="torch", seed=None, attn_weights=None, shard=None, fused_tail=True):
     """Drop-in for reference src/utils.py:35 `sample` (same positional order and defaults).
     Keyword-only extensions: noise ("torch" = consume torch's generator exactly like the reference; "philox" = counter-based
     noise generated in the kernels, keyed by `seed` -- None draws a fresh seed from torch's generator), attn_weights
-    (utils/modules.py:268), shard=(lo, total) for batch-sharded sampling (paella_amd.dist.sample_sharded)."""
+    (utils/modules.py:268), shard=(lo, total) for batch-sharded sampling (paella_amd.dist.sample_sharded), fused_tail (counter-based
+    mode only: take the categorical decision inside the head GEMM so the logits are never written; False keeps the two-kernel
+    path -- same tokens bit for bit, for A/B measurements)."""
     if cfg and unconditional_inputs is None:
         # the reference raises TypeError at src/utils.py:46 (`**None`); keep the failure, make it readable
         raise TypeError("cfg=%r requires unconditional_inputs" % (cfg,))
@@ -225,12 +240,12 @@ def sample(model, model_inputs, latent_shape, unconditional_inputs=None, steps=1
     else:
         cfgs = [None] * steps
     return _sample_core(model, model_inputs, unconditional_inputs, latent_shape, None, steps, renoise_steps, t_list, temperatures,
-                        cfgs, device, noise=noise, seed=seed, attn_weights=attn_weights, shard=shard)
+                        cfgs, device, noise=noise, seed=seed, attn_weights=attn_weights, shard=shard, fused_tail=fused_tail)
 
 
 def sample_distributed(model, model_inputs, unconditional_inputs, latent_shape, init_x=None, steps=12, renoise_steps=None,
                        temperature=(0.7, 0.3), cfg=(8.0, 8.0), t_start=1.0, t_end=0.0, sampling_conditional_steps=None, *,
-                       noise="torch", seed=None, attn_weights=None, shard=None):
+                       noise="torch", seed=None, attn_weights=None, shard=None, fused_tail=True):
     """Drop-in for reference src_distributed/utils.py:97 `sample` (init_x, cfg schedule, conditional-step cutoff)."""
     device = unconditional_inputs["byt5"].device
     if sampling_conditional_steps is None:
@@ -246,7 +261,7 @@ def sample_distributed(model, model_inputs, unconditional_inputs, latent_shape, 
             # `logits * cfgs[i] + logits_u * (1 - cfgs[i])` with a 0-dim fp32 tensor: (1 - cfg) is computed in fp32
             cfgs[i] = (float(sched[i]), float(1 - sched[i]))
     return _sample_core(model, model_inputs, unconditional_inputs, latent_shape, init_x, steps, renoise_steps, t_list, temperatures,
-                        cfgs, device, noise=noise, seed=seed, attn_weights=attn_weights, shard=shard)
+                        cfgs, device, noise=noise, seed=seed, attn_weights=attn_weights, shard=shard, fused_tail=fused_tail)
 
 
 class GraphSampler:

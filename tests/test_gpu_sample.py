@@ -416,3 +416,32 @@ def test_philox_shard_equals_unsharded(tiny):
     a = paella_amd.sample(tiny, to_dev(cs, DEV), (B, 16, 16), unconditional_inputs=to_dev(us, DEV), steps=2, renoise_steps=1, device=DEV, noise="philox")
     b = paella_amd.sample(tiny, to_dev(cs, DEV), (B, 16, 16), unconditional_inputs=to_dev(us, DEV), steps=2, renoise_steps=1, device=DEV, noise="philox")
     assert not torch.equal(a, b)
+
+
+@pytest.mark.parametrize("cfg_name,B,grid", [("UNET_TINY", 3, 16), ("UNET_MID", 2, 16), ("UNET_570M", 1, 32)])
+def test_fused_head_tail_is_bit_identical_to_the_two_kernel_path(built_lib, cfg_name, B, grid):
+    """out_mapper fused with the sampling tail (no logits tensor; SURVEY section 7 step 3, reference src/utils.py:44-50): same
+    tokens, bit for bit, as head GEMM -> logits -> tail kernel on the same Philox seed -- closed loop (every later step would
+    amplify a single differing token), with guidance (mix folded through the head), without guidance, and with an argmax step."""
+    cfg = dict(getattr(G, cfg_name))
+    m = paella_amd.Paella(**cfg)
+    weights_for(m, sum(cfg["blocks"]))
+    m = m.to(DEV)
+    cs, us = to_dev(cond_for(cfg, B, 3, 0, 1), DEV), to_dev(cond_for(cfg, B, 3, 0, 2), DEV)
+    kw = dict(steps=3, renoise_steps=2, device=DEV, noise="philox", seed=4242)
+    for extra in (dict(unconditional_inputs=us, cfg=8.0, temperature=(1.0, 0.3)),
+                  dict(unconditional_inputs=None, cfg=None, temperature=(0.9, 0.4)),
+                  dict(unconditional_inputs=None, cfg=None, temperature=(0.5, 0.0))):   # last step T = 0 -> argmax mode
+        a = paella_amd.sample(m, cs, (B, grid, grid), fused_tail=True, **kw, **extra)
+        b = paella_amd.sample(m, cs, (B, grid, grid), fused_tail=False, **kw, **extra)
+        assert torch.equal(a, b), "fused and two-kernel tails disagree at %d of %d positions" % (int((a != b).sum()), a.numel())
+        assert int(a.min()) >= 0 and int(a.max()) < cfg["num_labels"]
+    # sharded rows through the fused path too (row_offset reaches the GEMM epilogue's Philox counters)
+    if B >= 2:
+        from paella_amd.dist import shard_inputs
+        full = paella_amd.sample(m, cs, (B, grid, grid), unconditional_inputs=us, cfg=8.0, **kw)
+        part = paella_amd.sample(m, shard_inputs(cs, 1, B), (B - 1, grid, grid), unconditional_inputs=shard_inputs(us, 1, B), cfg=8.0, shard=(1, B), **kw)
+        same = int((part == full[1:]).sum())
+        print("%s fused shard rows 1..%d vs full batch: %d / %d identical" % (cfg_name, B - 1, same, part.numel()))
+        if cfg_name == "UNET_TINY":
+            assert same == part.numel()
