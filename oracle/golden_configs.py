@@ -27,3 +27,21 @@ VQ_F8 = dict(levels=3, bottleneck_blocks=12, c_hidden=384, c_latent=4, codebook_
 WEIGHT_SEED = 0
 COND_SEED = 2
 SAMPLER_SEED = 42
+
+
+import torch
+
+
+def train_step_inputs(cfg):
+    """Seeded inputs of one training step on the tiny config (shared with tests/test_training.py through the fixture)."""
+    B, H, W = 2, 16, 16
+    g = torch.Generator().manual_seed(21)
+    latents = torch.randint(0, cfg["num_labels"], (B, H, W), generator=g)
+    t = (1 - torch.rand(B, generator=g)).add(0.001).clamp(0.001, 1.0)
+    mask = (torch.rand(B, H, W, generator=g) <= t[:, None, None]).long()
+    random_x = torch.randint(0, cfg["num_labels"], (B, H, W), generator=g)
+    from paella_amd import synth
+    c = synth.synth_conditioning(B, 5, cfg["byt5_embd"], cfg["clip_embd"], seed=COND_SEED + 9, with_clip=True, n_clip_image=1)
+    return latents, t, mask, random_x, c
+
+

@@ -117,8 +117,52 @@ def save(name, **arrays):
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 
 
+def make_train_golden(ref):
+    """One training step of the REFERENCE (src_distributed/train.py:98-114 call sequence: add_noise -> get_loss_weight -> model(...)
+    in train mode with dropout 0.1 -> label-smoothed CE weighted by loss_weight -> backward) on the tiny config; stores the loss,
+    the logits and the gradient of every parameter as (norm, sum) plus a few small tensors in full."""
+    cfg = G.UNET_TINY
+    # src_distributed/modules.py carries get_loss_weight; same network as src/modules.py
+    mod = load_module(os.path.join(REF, "src_distributed", "modules.py"), "ref_dist_modules")
+    torch.manual_seed(0)
+    m = mod.Paella(**cfg)
+    sd = synth.synth_state_dict(m.state_dict(), seed=G.WEIGHT_SEED, n_blocks=sum(cfg["blocks"]))
+    m.load_state_dict(sd)
+    latents, t, mask, random_x, c = G.train_step_inputs(cfg)
+    out = {}
+    for tag, p_drop_seed in (("nodrop", None), ("drop", 1234)):
+        m.train()
+        for mm in m.modules():  # "nodrop": dropout off but still train mode (pure gradient check); "drop": the reference's 0.1
+            if isinstance(mm, nn.Dropout):
+                mm.p = 0.0 if p_drop_seed is None else cfg["dropout"]
+            if isinstance(mm, nn.MultiheadAttention):
+                mm.dropout = 0.0 if p_drop_seed is None else cfg["dropout"]
+        m.zero_grad(set_to_none=True)
+        noised, mk = m.add_noise(latents, t, mask=mask, random_x=random_x)
+        lw = m.get_loss_weight(t, mk)
+        if p_drop_seed is not None:
+            torch.manual_seed(p_drop_seed)
+        pred = m(noised, t, **c)
+        loss = nn.CrossEntropyLoss(label_smoothing=0.1, reduction='none')(pred, latents)
+        loss = ((loss * lw).sum(dim=[1, 2]) / lw.sum(dim=[1, 2])).mean()
+        loss.backward()
+        names = [k for k, _ in m.named_parameters()]
+        out[tag + "_loss"] = loss.detach()
+        out[tag + "_pred_sub"] = pred.detach()[:, ::4, ::2, ::2].contiguous()
+        out[tag + "_grad_norms"] = torch.stack([p.grad.norm() for _, p in m.named_parameters()])
+        out[tag + "_grad_sums"] = torch.stack([p.grad.double().sum().float() for _, p in m.named_parameters()])
+        for k in ("in_mapper.0.weight", "byt5_mapper.weight", "down_blocks.1.3.attention.attn.in_proj_weight", "down_blocks.1.1.channelwise.2.gamma",
+                  "down_blocks.0.1.mapper.weight", "up_blocks.0.0.depthwise.weight", "clf.1.weight", "out_mapper.1.weight", "up_blocks.1.6.1.weight"):
+            out[tag + "_grad:" + k] = dict(m.named_parameters())[k].grad.detach().clone()
+    save("train_tiny_step", names=np.array(names), checksum=np.array(synth.checksum(sd)), **out)
+
+
 def main():
     ref = import_reference()
+    if "--only-train" in sys.argv:
+        make_train_golden(ref)
+        return
+    make_train_golden(ref)
     with torch.no_grad():
         # ---- 1. forward, tiny ----
         cfg = G.UNET_TINY

@@ -42,7 +42,9 @@ struct SkPlan {
 };
 
 template <int WM, int WN, int TM, int TN, int PD, int APRO, bool TAIL = false>  // APRO: 0 none, 1 GRN scale/shift, 2 LayerNorm from row statistics; TAIL: fused sampling tail (head GEMM)
-__global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs g, SkPlan p, float* __restrict__ slabs,
+// The 32x32 tile is the batch-1 workhorse and wants 5 workgroups per CU (1280 resident): ask for <= 96 VGPRs there (the few
+// spills this costs the prologue variants sit in the flush path, never in the unit loop -- checked in the ISA).
+__global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 && PD == 2) ? 5 : 1) void gemm_nt_kernel(GemmArgs g, SkPlan p, float* __restrict__ slabs,
                                                                unsigned* __restrict__ tickets, unsigned slab_bytes) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16, BK = 32;
     constexpr int NW = WM * WN, NT = 64 * NW;
@@ -504,6 +506,33 @@ static inline long tiles_of_cfg(int c, int M, int N) {
     return (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
 }
 
+// Resident workgroups per CU of one instantiation (occupancy API, capped at 6: with ~106 SGPRs the hardware admits at most
+// floor(800 / 128) = 6 256-thread workgroups whatever the API says -- MI355X_MICROARCH.md "Residency").  A balanced-range launch
+// never uses more workgroups than fit at once: a second round would double the time of these ~20 us kernels.
+template <int WM, int WN, int TM, int TN, int PD, int APRO>
+static int occupancy_of() {
+    static int cached = -1;
+    if (cached < 0) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_nt_kernel<WM, WN, TM, TN, PD, APRO, false>, 64 * WM * WN, 0) != hipSuccess || n < 1) n = 2;
+        (void)hipGetLastError();
+        cached = n > 6 ? 6 : n;
+    }
+    return cached;
+}
+static int g_num_cus = 0;
+static int num_cus() {
+    if (g_num_cus <= 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) g_num_cus = prop.multiProcessorCount;
+        else g_num_cus = 256;
+        (void)hipGetLastError();
+    }
+    return g_num_cus;
+}
+static int gemm_occupancy(int cfg, int apro);
+
 // Tile / workgroup-count choice, fitted to tools/gemm_tune.py sweeps on MI355X (profiles/r02_gemm_tile_sweep.txt).
 // Returns the tile config and G (number of workgroups = number of contiguous unit ranges).  What the sweeps show:
 //  * >= 1024 tiles of 128x128: one tile per workgroup, 8 waves (cfg 10): 127-133 TFLOP/s at any K;
@@ -630,6 +659,7 @@ static int launch_gemm_cfg_impl(const GemmArgs& g, int cfg, int splitk, void* ws
     const bool have_ws = ws && ws_bytes > kGemmTicketBytes;
     const size_t slab_cap = have_ws ? ws_bytes - kGemmTicketBytes : 0;
     unsigned G = 0;
+    const bool heuristic = cfg < 0;
     if (cfg < 0) {
         choose_config(g.M, g.N, g.K, slab_cap, &cfg, &G);
     } else {
@@ -649,6 +679,10 @@ static int launch_gemm_cfg_impl(const GemmArgs& g, int cfg, int splitk, void* ws
     p.U = (unsigned)U;
     if (G < 1) G = 1;
     if (G > p.U) G = p.U;
+    if (heuristic && G != (unsigned)T) {  // balanced ranges: every workgroup resident at once
+        const unsigned cap = (unsigned)(gemm_occupancy(cfg, g.a_scale ? 1 : (g.ln_stats ? 2 : 0)) * num_cus());
+        if (G > cap) G = cap >= (unsigned)T || T > 4ull * cap ? cap : (unsigned)T;
+    }
     if (g.ln_stats && p.tiles_m > 1) {
         // the LayerNorm-on-load variant computes its row statistics once per workgroup: keep every range inside one tile
         unsigned S = G / (unsigned)T;
@@ -731,6 +765,20 @@ int launch_gemm_tail(const GemmArgs& g, hipStream_t st) {
     LAUNCH_CHECK_RET();
     return PAELLA_OK;
 }
+
+#define OCC_CASE(id, WMv, WNv, TMv, TNv, PDv) \
+    case id: return apro == 1 ? occupancy_of<WMv, WNv, TMv, TNv, PDv, 1>() : (apro == 2 ? occupancy_of<WMv, WNv, TMv, TNv, PDv, 2>() : occupancy_of<WMv, WNv, TMv, TNv, PDv, 0>());
+static int gemm_occupancy(int cfg, int apro) {
+    switch (cfg) {
+        OCC_CASE(0, 2, 2, 4, 4, 1) OCC_CASE(1, 2, 2, 4, 2, 2) OCC_CASE(2, 2, 2, 2, 2, 2) OCC_CASE(3, 2, 2, 2, 1, 2) OCC_CASE(4, 2, 2, 1, 2, 2)
+        OCC_CASE(5, 2, 2, 1, 1, 2) OCC_CASE(6, 1, 4, 1, 1, 2) OCC_CASE(7, 1, 4, 1, 2, 2) OCC_CASE(8, 1, 4, 2, 2, 2) OCC_CASE(9, 4, 2, 2, 4, 1)
+        OCC_CASE(10, 2, 4, 4, 2, 1) OCC_CASE(11, 4, 1, 2, 2, 2) OCC_CASE(12, 4, 1, 2, 4, 2) OCC_CASE(13, 4, 1, 1, 4, 2) OCC_CASE(14, 4, 2, 2, 2, 2)
+        OCC_CASE(15, 8, 1, 2, 2, 2) OCC_CASE(16, 8, 1, 2, 4, 1) OCC_CASE(17, 8, 1, 1, 4, 2) OCC_CASE(18, 2, 2, 2, 2, 1) OCC_CASE(19, 2, 2, 1, 1, 1)
+        OCC_CASE(20, 4, 1, 2, 4, 1) OCC_CASE(21, 4, 1, 1, 2, 2) OCC_CASE(22, 2, 2, 1, 4, 2) OCC_CASE(23, 1, 4, 2, 1, 2)
+        default: return 2;
+    }
+}
+#undef OCC_CASE
 
 int launch_gemm(const GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t st) {
     return launch_gemm_cfg(g, -1, 1, ws, ws_bytes, st);

@@ -33,7 +33,8 @@ __device__ __forceinline__ float u01_half_open(uint32_t bits) { return (float)(b
 
 // Categorical draw in the log domain (Gumbel-max): token = argmax_i (x_i - log q_i), q ~ Exp(1), i.e. log q = log(-log u).
 // == argmax softmax(x) / q == torch.multinomial(softmax(x), 1) in distribution; no exp, no division, no row max needed.
-__device__ __forceinline__ float log_exp1(uint32_t bits) { return __logf(-logf(u01_open(bits))); }
+// (hardware log2 for both logarithms: this runs once per LOGIT, 8192 x positions x steps, inside the head GEMM's epilogue)
+__device__ __forceinline__ float log_exp1(uint32_t bits) { return __logf(-__logf(u01_open(bits))); }
 // The score both tails maximise in the counter-based mode.  ONE definition: the fused (GEMM epilogue) and unfused (tail kernel)
 // paths must round identically.  contract(off): no FMA may merge the division's multiply-free result with the subtraction.
 __device__ __forceinline__ float tail_score_gumbel(float logit, float temperature, float log_q) {

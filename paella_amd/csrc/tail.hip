@@ -119,27 +119,36 @@ __global__ __launch_bounds__(256) void sample_tail_kernel(TailArgs a) {
 }
 
 // Second half of the FUSED tail: the head GEMM's epilogue (gemm.hip, TAIL instantiations) left, per row and column tile, the best
-// (score, label) of that tile; pick the row's winner in tile order (first index wins ties -> identical to the one-kernel tail),
-// renoise, store the token.  One thread per row.
+// (score, label) of that tile; pick the row's winner (first index wins ties -> identical to the one-kernel tail under any
+// reduction order), renoise, store the token.  One wave per row: lane t reads tile t (coalesced), xor-shuffle argmax.
 __global__ __launch_bounds__(256) void tail_finalize_kernel(TailArgs a, const float* __restrict__ part_score, const int* __restrict__ part_idx,
                                                             int tiles_n) {
-    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= a.rows) return;
-    const uint64_t seed = a.seed + (a.seed_ptr ? *a.seed_ptr : 0ull);
     float best = -INFINITY;
     int best_i = 0x7fffffff;
     const float* ps = part_score + row * tiles_n;
     const int* pi = part_idx + row * tiles_n;
-    for (int t = 0; t < tiles_n; ++t) argmax_update(best, best_i, ps[t], pi[t]);
-    if (best_i == 0x7fffffff) best_i = 0;
-    int64_t tok = best_i;
-    if (a.sampled_out) a.sampled_out[row] = tok;
-    a.tokens_out[row] = renoise_token(a, seed, row, tok);
+    for (int t = lane; t < tiles_n; t += 64) argmax_update(best, best_i, ps[t], pi[t]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(best_i, o, 64);
+        argmax_update(best, best_i, ov, oi);
+    }
+    if (lane == 0) {
+        const uint64_t seed = a.seed + (a.seed_ptr ? *a.seed_ptr : 0ull);
+        if (best_i == 0x7fffffff) best_i = 0;
+        int64_t tok = best_i;
+        if (a.sampled_out) a.sampled_out[row] = tok;
+        a.tokens_out[row] = renoise_token(a, seed, row, tok);
+    }
 }
 
 int launch_tail_finalize(const TailArgs& a, const float* part_score, const int* part_idx, int tiles_n, hipStream_t st) {
     if (a.rows <= 0) return PAELLA_OK;
-    hipLaunchKernelGGL(tail_finalize_kernel, dim3((unsigned)((a.rows + 255) / 256)), dim3(256), 0, st, a, part_score, part_idx, tiles_n);
+    hipLaunchKernelGGL(tail_finalize_kernel, dim3((unsigned)((a.rows + 3) / 4)), dim3(256), 0, st, a, part_score, part_idx, tiles_n);
     LAUNCH_CHECK_RET();
     return PAELLA_OK;
 }

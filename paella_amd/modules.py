@@ -75,7 +75,7 @@ class Paella(nn.Module):
                          c_hidden=list(c_hidden), nhead=list(nhead), blocks=list(blocks), level_config=list(level_config),
                          clip_embd=clip_embd, byt5_embd=byt5_embd, clip_seq_len=clip_seq_len, kernel_size=kernel_size,
                          self_attn=bool(self_attn))
-        # dropout is accepted for signature compatibility; the HIP path is inference-only (dropout = identity in eval)
+        # dropout acts in train mode only (paella_amd/training.py); the HIP engine serves eval mode, where it is the identity
         self.dropout = dropout
         n_levels = len(c_hidden)
         if not (len(nhead) == len(blocks) == len(level_config) == n_levels):
@@ -127,6 +127,10 @@ class Paella(nn.Module):
         self._handle = None
         self._loaded_sig = None
         self._ws = None
+        # Constructed in EVAL mode (an nn.Module normally starts in train mode): eval = the hand-written HIP engine, which is what
+        # sampling needs; `model.train()` -- the switch the reference's training loops flip (src/train.py:47,
+        # src_distributed/train.py:73,140,172) -- selects the differentiable torch-op evaluation of paella_amd/training.py.
+        self.train(False)
 
     # ------------------------------------------------------------------ init (same distributions as src/modules.py:189-210)
     @torch.no_grad()
@@ -139,6 +143,13 @@ class Paella(nn.Module):
                 nn.init.xavier_uniform_(p)
             else:
                 p.zero_()
+        for level in self.up_blocks:  # the reference's _init_weights touches Conv2d / Linear only: the up-samplers' ConvTranspose2d
+            for b in level:           # keeps torch's default init (kaiming-uniform weight, uniform bias)
+                if b.kind == 'U':
+                    cv = b._modules["1"]
+                    ref = nn.ConvTranspose2d(cv.weight.size(0), cv.weight.size(1), kernel_size=2, stride=2)
+                    cv.weight.copy_(ref.weight)
+                    cv.bias.copy_(ref.bias)
         for m in (self.byt5_mapper, self.clip_mapper, self.clip_image_mapper):
             nn.init.normal_(m.weight, std=0.02)
         nn.init.xavier_uniform_(self.embedding._modules["1"].weight, 0.02)
@@ -167,6 +178,12 @@ class Paella(nn.Module):
 
     def _signature(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def refresh(self):
+        """Force the native engine to reload every tensor on the next call.  Needed only after edits torch does not version
+        (`p.data *= ...`, the idiom the reference itself uses at init); optimizer steps, `load_state_dict`, `.to()` and ordinary
+        in-place ops are detected automatically."""
+        self._loaded_sig = None
 
     def _engine(self):
         """Create / refresh the native model: (re)load every tensor when parameters moved or changed."""
@@ -388,12 +405,17 @@ class Paella(nn.Module):
         return out
 
     def forward(self, x, r, byt5, clip=None, clip_image=None, x_cat=None, **kwargs):
-        """reference src/modules.py:263-275 (kwargs -> attn_weights as utils/modules.py:268). Inference only."""
-        if x_cat is not None:
-            x = torch.cat([x, x_cat], dim=1)
+        """reference src/modules.py:263-275 (kwargs -> attn_weights as utils/modules.py:268).
+        eval mode (default): the HIP engine, no autograd graph.  train mode (`model.train()`): the differentiable torch-op
+        evaluation of paella_amd/training.py, so `loss.backward()` works as in src/train.py:63-66."""
         unknown = set(kwargs) - {"attn_weights"}
         if unknown:
             raise TypeError("unsupported attention kwargs: %s" % sorted(unknown))
+        if self.training:
+            from .training import forward_autograd
+            return forward_autograd(self, x, r, byt5, clip, clip_image, x_cat, kwargs.get("attn_weights"))
+        if x_cat is not None:
+            x = torch.cat([x, x_cat], dim=1)
         cond = self.prepare_cond(byt5, clip, clip_image)
         return self.forward_prepared(x, r, cond, attn_weights=kwargs.get("attn_weights"))
 
