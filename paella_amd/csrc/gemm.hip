@@ -41,18 +41,21 @@ struct SkPlan {
     unsigned U;            // tiles_m * tiles_n * KT work units
 };
 
-template <int WM, int WN, int TM, int TN, int PD, int APRO, bool TAIL = false>  // APRO: 0 none, 1 GRN scale/shift, 2 LayerNorm from row statistics; TAIL: fused sampling tail (head GEMM)
+template <int WM, int WN, int TM, int TN, int PD, int APRO, bool TAIL = false, int BK = 32>  // BK: K step (32 or 64 floats per LDS row); APRO: 0 none, 1 GRN scale/shift, 2 LayerNorm from row statistics; TAIL: fused sampling tail (head GEMM)
 // The 32x32 tile is the batch-1 workhorse and wants 5 workgroups per CU (1280 resident): ask for <= 96 VGPRs there (the few
 // spills this costs the prologue variants sit in the flush path, never in the unit loop -- checked in the ISA).
-__global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 && PD == 2) ? 5 : 1) void gemm_nt_kernel(GemmArgs g, SkPlan p, float* __restrict__ slabs,
+__global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 && PD == 2 && BK == 32) ? 5 : 1) void gemm_nt_kernel(GemmArgs g, SkPlan p, float* __restrict__ slabs,
                                                                unsigned* __restrict__ tickets, unsigned slab_bytes) {
-    constexpr int BM = WM * TM * 16, BN = WN * TN * 16, BK = 32;
+    constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+    constexpr int SL = BK / 4;     // 16-byte slots per LDS row; slot s of row r lives at s ^ (r & (SL - 1)): conflict-free ds_write_b128 / ds_read_b128
+    constexpr int KG = BK / 16;    // 16-wide k groups per K step (4 MFMA k-instructions each)
     constexpr int NW = WM * WN, NT = 64 * NW;
-    constexpr int RP = NT / 8;  // rows staged per pass: 8 threads (one float4 each) cover a 32-float row
-    constexpr int LA = (BM * 8 + NT - 1) / NT, LB = (BN * 8 + NT - 1) / NT;
+    constexpr int RP = NT / SL;  // rows staged per pass: SL threads (one float4 each) cover a BK-float row
+    constexpr int LA = (BM * SL + NT - 1) / NT, LB = (BN * SL + NT - 1) / NT;
     constexpr int TILE_FLOATS = (BM + BN) * BK;
     static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
     static_assert(PD == 1 || PD == 2, "prefetch ring depth 1 or 2");
+    static_assert(BK == 32 || BK == 64, "K step of 32 or 64");
     // one LDS object: two tile stages + 16 floats for the ticket broadcast (the NEXT unit's tile is already staged when a
     // segment is flushed, so the flag cannot live inside the stages)
     constexpr int TAIL_FLOATS = TAIL ? BM * WN * 2 : 0;  // fused tail: per row and wave column, the best (score, label)
@@ -78,7 +81,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 &
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform -> SGPR arithmetic for wm / wn / slab bases
     const int wm = wave / WN, wn = wave % WN;
     const int r16 = lane & 15, kq = lane >> 4;
-    const int ldrow = tid >> 3, ldc4 = tid & 7;
+    const int ldrow = tid / SL, ldc4 = tid % SL;
 
     f32x4 acc[TM][TN];
 #pragma unroll
@@ -131,9 +134,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 &
             const int gmc = min(m0 + ldrow + i * RP, g.M - 1);
             const float* stp = g.ln_stats + (size_t)gmc * g.ln_nblk * 2;
             double s = 0.0, q = 0.0;
-            for (int j = ldc4; j < g.ln_nblk; j += 8) { s += (double)stp[2 * j]; q += (double)stp[2 * j + 1]; }
+            for (int j = ldc4; j < g.ln_nblk; j += SL) { s += (double)stp[2 * j]; q += (double)stp[2 * j + 1]; }
 #pragma unroll
-            for (int o = 1; o < 8; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+            for (int o = 1; o < SL; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
             const double mean = s / (double)g.K;
             const double var = q / (double)g.K - mean * mean;
             ln_mu[i] = (float)mean;
@@ -163,12 +166,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 &
             if (APRO == 1) v = v * r.s[i] + r.t;
             if (APRO == 2) v = (v - ln_mu[i]) * ln_rs[i];
             if (!r.kok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (LA * RP == BM || row < BM) *reinterpret_cast<f32x4*>(As + row * BK + ((ldc4 ^ (row & 7)) << 2)) = v;
+            if (LA * RP == BM || row < BM) *reinterpret_cast<f32x4*>(As + row * BK + ((ldc4 ^ (row & (SL - 1))) << 2)) = v;
         }
 #pragma unroll
         for (int i = 0; i < LB; ++i) {
             const int row = ldrow + i * RP;
-            if (LB * RP == BN || row < BN) *reinterpret_cast<f32x4*>(Bs + row * BK + ((ldc4 ^ (row & 7)) << 2)) = r.b[i];
+            if (LB * RP == BN || row < BN) *reinterpret_cast<f32x4*>(Bs + row * BK + ((ldc4 ^ (row & (SL - 1))) << 2)) = r.b[i];
         }
     };
     // A 1x1 wave tile alternates two accumulators so its MFMAs are never back-to-back dependent
@@ -182,30 +185,32 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 &
         // per tile); the other big ones: per 16-k group (VGPRs)
         constexpr bool FRAG_FIRST = (TM * TN <= 2) || (NW == 8 && TM + TN <= 6 && PD == 1);
         if constexpr (FRAG_FIRST) {
-            f32x4 af[2][TM], bf[2][TN];
+            f32x4 af[KG][TM], bf[KG][TN];
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
+            for (int kk = 0; kk < KG; ++kk) {
                 const int c4 = kk * 4 + kq;
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     const int row = (wm * TM + i) * 16 + r16;
-                    af[kk][i] = *reinterpret_cast<const f32x4*>(As + row * BK + ((c4 ^ (row & 7)) << 2));
+                    af[kk][i] = *reinterpret_cast<const f32x4*>(As + row * BK + ((c4 ^ (row & (SL - 1))) << 2));
                 }
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const int row = (wn * TN + j) * 16 + r16;
-                    bf[kk][j] = *reinterpret_cast<const f32x4*>(Bs + row * BK + ((c4 ^ (row & 7)) << 2));
+                    bf[kk][j] = *reinterpret_cast<const f32x4*>(Bs + row * BK + ((c4 ^ (row & (SL - 1))) << 2));
                 }
             }
             if (DUAL) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[0][0][e], af[0][0][e], acc[0][0], 0, 0, 0);
-                    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[1][0][e], af[1][0][e], acc2, 0, 0, 0);
-                }
+                for (int kk = 0; kk < KG; kk += 2)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[kk][0][e], af[kk][0][e], acc[0][0], 0, 0, 0);
+                        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[kk + 1][0][e], af[kk + 1][0][e], acc2, 0, 0, 0);
+                    }
             } else {
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
+                for (int kk = 0; kk < KG; ++kk)
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -216,18 +221,18 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 &
             }
         } else {
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
+            for (int kk = 0; kk < KG; ++kk) {
                 f32x4 af[TM], bf[TN];
                 const int c4 = kk * 4 + kq;
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     const int row = (wm * TM + i) * 16 + r16;
-                    af[i] = *reinterpret_cast<const f32x4*>(As + row * BK + ((c4 ^ (row & 7)) << 2));
+                    af[i] = *reinterpret_cast<const f32x4*>(As + row * BK + ((c4 ^ (row & (SL - 1))) << 2));
                 }
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const int row = (wn * TN + j) * 16 + r16;
-                    bf[j] = *reinterpret_cast<const f32x4*>(Bs + row * BK + ((c4 ^ (row & 7)) << 2));
+                    bf[j] = *reinterpret_cast<const f32x4*>(Bs + row * BK + ((c4 ^ (row & (SL - 1))) << 2));
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
@@ -459,46 +464,52 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 &
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
-struct TileCfg { int wm, wn, tm, tn, pd; };
+struct TileCfg { int wm, wn, tm, tn, pd, bk; };
 // BM = wm*tm*16, BN = wn*tn*16; ids are stable (tests and tools name them)
 static const TileCfg kCfgs[] = {
-    {2, 2, 4, 4, 1},  // 0: 128x128
-    {2, 2, 4, 2, 2},  // 1: 128x64
-    {2, 2, 2, 2, 2},  // 2: 64x64
-    {2, 2, 2, 1, 2},  // 3: 64x32
-    {2, 2, 1, 2, 2},  // 4: 32x64
-    {2, 2, 1, 1, 2},  // 5: 32x32
-    {1, 4, 1, 1, 2},  // 6: 16x64
-    {1, 4, 1, 2, 2},  // 7: 16x128
-    {1, 4, 2, 2, 2},  // 8: 32x128
-    {4, 2, 2, 4, 1},  // 9: 128x128, 8 waves (32x64 wave tiles, fragment-first): the large-problem default
-    {2, 4, 4, 2, 1},  // 10: 128x128, 8 waves (64x32 wave tiles, fragment-first)
-    {4, 1, 2, 2, 2},  // 11: 128x32, waves stacked along M (32x32 wave tiles): M-covering for M <= 128
-    {4, 1, 2, 4, 2},  // 12: 128x64, waves stacked along M (32x64 wave tiles)
-    {4, 1, 1, 4, 2},  // 13: 64x64, waves stacked along M (16x64 wave tiles): M-covering for M <= 64
-    {4, 2, 2, 2, 2},  // 14: 128x64, 8 waves (32x32 wave tiles)
-    {8, 1, 2, 2, 2},  // 15: 256x32, 8 waves stacked along M
-    {8, 1, 2, 4, 1},  // 16: 256x64, 8 waves stacked along M (32x64 wave tiles)
-    {8, 1, 1, 4, 2},  // 17: 128x64, 8 waves stacked along M (16x64 wave tiles)
-    {2, 2, 2, 2, 1},  // 18: 64x64, 1-deep prefetch
-    {2, 2, 1, 1, 1},  // 19: 32x32, 1-deep prefetch
-    {4, 1, 2, 4, 1},  // 20: 128x64 stacked, 1-deep prefetch
-    {4, 1, 1, 2, 2},  // 21: 64x32, waves stacked along M (16x32 wave tiles)
-    {2, 2, 1, 4, 2},  // 22: 32x128 (16x64 wave tiles): M-covering for M <= 32
-    {1, 4, 2, 1, 2},  // 23: 32x64, waves along N (32x16 wave tiles)
+    {2, 2, 4, 4, 1, 32},  // 0: 128x128
+    {2, 2, 4, 2, 2, 32},  // 1: 128x64
+    {2, 2, 2, 2, 2, 32},  // 2: 64x64
+    {2, 2, 2, 1, 2, 32},  // 3: 64x32
+    {2, 2, 1, 2, 2, 32},  // 4: 32x64
+    {2, 2, 1, 1, 2, 32},  // 5: 32x32
+    {1, 4, 1, 1, 2, 32},  // 6: 16x64
+    {1, 4, 1, 2, 2, 32},  // 7: 16x128
+    {1, 4, 2, 2, 2, 32},  // 8: 32x128
+    {4, 2, 2, 4, 1, 32},  // 9: 128x128, 8 waves (32x64 wave tiles, fragment-first): the large-problem default
+    {2, 4, 4, 2, 1, 32},  // 10: 128x128, 8 waves (64x32 wave tiles, fragment-first)
+    {4, 1, 2, 2, 2, 32},  // 11: 128x32, waves stacked along M (32x32 wave tiles): M-covering for M <= 128
+    {4, 1, 2, 4, 2, 32},  // 12: 128x64, waves stacked along M (32x64 wave tiles)
+    {4, 1, 1, 4, 2, 32},  // 13: 64x64, waves stacked along M (16x64 wave tiles): M-covering for M <= 64
+    {4, 2, 2, 2, 2, 32},  // 14: 128x64, 8 waves (32x32 wave tiles)
+    {8, 1, 2, 2, 2, 32},  // 15: 256x32, 8 waves stacked along M
+    {8, 1, 2, 4, 1, 32},  // 16: 256x64, 8 waves stacked along M (32x64 wave tiles)
+    {8, 1, 1, 4, 2, 32},  // 17: 128x64, 8 waves stacked along M (16x64 wave tiles)
+    {2, 2, 2, 2, 1, 32},  // 18: 64x64, 1-deep prefetch
+    {2, 2, 1, 1, 1, 32},  // 19: 32x32, 1-deep prefetch
+    {4, 1, 2, 4, 1, 32},  // 20: 128x64 stacked, 1-deep prefetch
+    {4, 1, 1, 2, 2, 32},  // 21: 64x32, waves stacked along M (16x32 wave tiles)
+    {2, 2, 1, 4, 2, 32},  // 22: 32x128 (16x64 wave tiles): M-covering for M <= 32
+    {1, 4, 2, 1, 2, 32},  // 23: 32x64, waves along N (32x16 wave tiles)
+    {2, 2, 1, 1, 2, 64},  // 24: 32x32, K step 64 (half the barriers / address arithmetic per FLOP)
+    {2, 2, 1, 1, 1, 64},  // 25: 32x32, K step 64, 1-deep prefetch
+    {2, 2, 2, 2, 1, 64},  // 26: 64x64, K step 64, 1-deep prefetch
+    {4, 1, 2, 2, 1, 64},  // 27: 128x32 stacked, K step 64, 1-deep prefetch
+    {2, 2, 1, 2, 1, 64},  // 28: 32x64, K step 64, 1-deep prefetch
+    {4, 2, 2, 2, 1, 64},  // 29: 128x64, 8 waves, K step 64, 1-deep prefetch
 };
 static const int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 int gemm_num_tile_configs() { return kNumCfgs; }
 
-template <int WM, int WN, int TM, int TN, int PD>
+template <int WM, int WN, int TM, int TN, int PD, int BK>
 static void launch_one(const GemmArgs& g, const SkPlan& p, unsigned G, float* slabs, unsigned* tickets, unsigned slab_bytes, hipStream_t st) {
     constexpr int NT = 64 * WM * WN;
     if (g.a_scale)
-        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, PD, 1>), dim3(G), dim3(NT), 0, st, g, p, slabs, tickets, slab_bytes);
+        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, PD, 1, false, BK>), dim3(G), dim3(NT), 0, st, g, p, slabs, tickets, slab_bytes);
     else if (g.ln_stats)
-        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, PD, 2>), dim3(G), dim3(NT), 0, st, g, p, slabs, tickets, slab_bytes);
+        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, PD, 2, false, BK>), dim3(G), dim3(NT), 0, st, g, p, slabs, tickets, slab_bytes);
     else
-        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, PD, 0>), dim3(G), dim3(NT), 0, st, g, p, slabs, tickets, slab_bytes);
+        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, PD, 0, false, BK>), dim3(G), dim3(NT), 0, st, g, p, slabs, tickets, slab_bytes);
 }
 
 static inline long tiles_of_cfg(int c, int M, int N) {
@@ -509,12 +520,12 @@ static inline long tiles_of_cfg(int c, int M, int N) {
 // Resident workgroups per CU of one instantiation (occupancy API, capped at 6: with ~106 SGPRs the hardware admits at most
 // floor(800 / 128) = 6 256-thread workgroups whatever the API says -- MI355X_MICROARCH.md "Residency").  A balanced-range launch
 // never uses more workgroups than fit at once: a second round would double the time of these ~20 us kernels.
-template <int WM, int WN, int TM, int TN, int PD, int APRO>
+template <int WM, int WN, int TM, int TN, int PD, int APRO, int BK>
 static int occupancy_of() {
     static int cached = -1;
     if (cached < 0) {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_nt_kernel<WM, WN, TM, TN, PD, APRO, false>, 64 * WM * WN, 0) != hipSuccess || n < 1) n = 2;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_nt_kernel<WM, WN, TM, TN, PD, APRO, false, BK>, 64 * WM * WN, 0) != hipSuccess || n < 1) n = 2;
         (void)hipGetLastError();
         cached = n > 6 ? 6 : n;
     }
@@ -672,7 +683,7 @@ static int launch_gemm_cfg_impl(const GemmArgs& g, int cfg, int splitk, void* ws
     SkPlan p;
     p.tiles_m = (g.M + BM - 1) / BM;
     p.tiles_n = (g.N + BN - 1) / BN;
-    p.KT = (g.K + 31) / 32;
+    p.KT = (g.K + tc.bk - 1) / tc.bk;
     const unsigned long long T = (unsigned long long)p.tiles_m * p.tiles_n;
     const unsigned long long U = T * (unsigned long long)p.KT;
     if (U >= (1ull << 31)) { paella_set_error("gemm: problem too large (%llu work units)", U); return PAELLA_ERR_ARG; }
@@ -702,7 +713,9 @@ static int launch_gemm_cfg_impl(const GemmArgs& g, int cfg, int splitk, void* ws
     unsigned* tickets = have_ws ? reinterpret_cast<unsigned*>(ws) : nullptr;
     float* slabs = have_ws ? reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + kGemmTicketBytes) : nullptr;
 #define GEMM_CASE(id, WMv, WNv, TMv, TNv, PDv) \
-    case id: launch_one<WMv, WNv, TMv, TNv, PDv>(g, p, G, slabs, tickets, slab_bytes, st); break;
+    case id: launch_one<WMv, WNv, TMv, TNv, PDv, 32>(g, p, G, slabs, tickets, slab_bytes, st); break;
+#define GEMM_CASE64(id, WMv, WNv, TMv, TNv, PDv) \
+    case id: launch_one<WMv, WNv, TMv, TNv, PDv, 64>(g, p, G, slabs, tickets, slab_bytes, st); break;
     switch (cfg) {
         GEMM_CASE(0, 2, 2, 4, 4, 1)
         GEMM_CASE(1, 2, 2, 4, 2, 2)
@@ -728,9 +741,16 @@ static int launch_gemm_cfg_impl(const GemmArgs& g, int cfg, int splitk, void* ws
         GEMM_CASE(21, 4, 1, 1, 2, 2)
         GEMM_CASE(22, 2, 2, 1, 4, 2)
         GEMM_CASE(23, 1, 4, 2, 1, 2)
+        GEMM_CASE64(24, 2, 2, 1, 1, 2)
+        GEMM_CASE64(25, 2, 2, 1, 1, 1)
+        GEMM_CASE64(26, 2, 2, 2, 2, 1)
+        GEMM_CASE64(27, 4, 1, 2, 2, 1)
+        GEMM_CASE64(28, 2, 2, 1, 2, 1)
+        GEMM_CASE64(29, 4, 2, 2, 2, 1)
         default: paella_set_error("gemm: bad tile config %d", cfg); return PAELLA_ERR_ARG;
     }
 #undef GEMM_CASE
+#undef GEMM_CASE64
     LAUNCH_CHECK_RET();
     return PAELLA_OK;
 }
@@ -766,8 +786,9 @@ int launch_gemm_tail(const GemmArgs& g, hipStream_t st) {
     return PAELLA_OK;
 }
 
-#define OCC_CASE(id, WMv, WNv, TMv, TNv, PDv) \
-    case id: return apro == 1 ? occupancy_of<WMv, WNv, TMv, TNv, PDv, 1>() : (apro == 2 ? occupancy_of<WMv, WNv, TMv, TNv, PDv, 2>() : occupancy_of<WMv, WNv, TMv, TNv, PDv, 0>());
+#define OCC_CASE_BK(id, WMv, WNv, TMv, TNv, PDv, BKv) \
+    case id: return apro == 1 ? occupancy_of<WMv, WNv, TMv, TNv, PDv, 1, BKv>() : (apro == 2 ? occupancy_of<WMv, WNv, TMv, TNv, PDv, 2, BKv>() : occupancy_of<WMv, WNv, TMv, TNv, PDv, 0, BKv>());
+#define OCC_CASE(id, WMv, WNv, TMv, TNv, PDv) OCC_CASE_BK(id, WMv, WNv, TMv, TNv, PDv, 32)
 static int gemm_occupancy(int cfg, int apro) {
     switch (cfg) {
         OCC_CASE(0, 2, 2, 4, 4, 1) OCC_CASE(1, 2, 2, 4, 2, 2) OCC_CASE(2, 2, 2, 2, 2, 2) OCC_CASE(3, 2, 2, 2, 1, 2) OCC_CASE(4, 2, 2, 1, 2, 2)
@@ -775,10 +796,13 @@ static int gemm_occupancy(int cfg, int apro) {
         OCC_CASE(10, 2, 4, 4, 2, 1) OCC_CASE(11, 4, 1, 2, 2, 2) OCC_CASE(12, 4, 1, 2, 4, 2) OCC_CASE(13, 4, 1, 1, 4, 2) OCC_CASE(14, 4, 2, 2, 2, 2)
         OCC_CASE(15, 8, 1, 2, 2, 2) OCC_CASE(16, 8, 1, 2, 4, 1) OCC_CASE(17, 8, 1, 1, 4, 2) OCC_CASE(18, 2, 2, 2, 2, 1) OCC_CASE(19, 2, 2, 1, 1, 1)
         OCC_CASE(20, 4, 1, 2, 4, 1) OCC_CASE(21, 4, 1, 1, 2, 2) OCC_CASE(22, 2, 2, 1, 4, 2) OCC_CASE(23, 1, 4, 2, 1, 2)
+        OCC_CASE_BK(24, 2, 2, 1, 1, 2, 64) OCC_CASE_BK(25, 2, 2, 1, 1, 1, 64) OCC_CASE_BK(26, 2, 2, 2, 2, 1, 64) OCC_CASE_BK(27, 4, 1, 2, 2, 1, 64)
+        OCC_CASE_BK(28, 2, 2, 1, 2, 1, 64) OCC_CASE_BK(29, 4, 2, 2, 2, 1, 64)
         default: return 2;
     }
 }
 #undef OCC_CASE
+#undef OCC_CASE_BK
 
 int launch_gemm(const GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t st) {
     return launch_gemm_cfg(g, -1, 1, ws, ws_bytes, st);

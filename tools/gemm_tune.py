@@ -47,14 +47,15 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--big-only", action="store_true", help="only the large-tile candidates without split-K")
-    ap.add_argument("--only", default=None, help="substring filter on the shape name")
+    ap.add_argument("--only", default=None, help="substring filter on the shape name (comma-separated alternatives)")
+    ap.add_argument("--cfgs", default=None, help="comma-separated tile configs to sweep (default: all that fit)")
     a = ap.parse_args()
     lib = _lib.load()
     st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     ws = _lib.new_workspace(256 << 20, "cuda")
     results = {}
     for name, (M, N, K) in SHAPES.items():
-        if a.only and a.only not in name:
+        if a.only and not any(o in name for o in a.only.split(",")):
             continue
         # cold weights without a flush kernel: rotate over enough distinct copies of W to exceed the 256 MiB MALL,
         # exactly like consecutive layers of the model; activations stay warm.  One event pair brackets a whole
@@ -68,11 +69,13 @@ def main():
         # workgroups walking balanced contiguous (tile, K-step) ranges
         tile_of = {0: (128, 128), 1: (128, 64), 2: (64, 64), 3: (64, 32), 4: (32, 64), 5: (32, 32), 6: (16, 64), 7: (16, 128), 8: (32, 128),
                    9: (128, 128), 10: (128, 128), 11: (128, 32), 12: (128, 64), 13: (64, 64), 14: (128, 64), 15: (256, 32), 16: (256, 64),
-                   17: (128, 64), 18: (64, 64), 19: (32, 32), 20: (128, 64), 21: (64, 32), 22: (32, 128), 23: (32, 64)}
+                   17: (128, 64), 18: (64, 64), 19: (32, 32), 20: (128, 64), 21: (64, 32), 22: (32, 128), 23: (32, 64),
+                   24: (32, 32), 25: (32, 32), 26: (64, 64), 27: (128, 32), 28: (32, 64), 29: (128, 64)}
+        bk_of = {c: (64 if c >= 24 else 32) for c in tile_of}
         def fits(c):  # skip tiles that waste more than half their rows on this M
             bm = tile_of[c][0]
             return bm <= 2 * max(M, 16) or c in (2, 5)
-        cands = [c for c in tile_of if fits(c)]
+        cands = [c for c in tile_of if fits(c) and (a.cfgs is None or str(c) in a.cfgs.split(","))]
         variants = [(-1, 1)] + [(c, s) for c in cands for s in (1, 2, 3, 4, 6, 8, 12, 16)] + \
                    [(c, -G) for c in cands for G in (256, 384, 512, 640, 768, 1024, 1280, 1536, 2048)]
         if a.big_only:
@@ -85,7 +88,7 @@ def main():
             if sk < 0:
                 bm, bn = tile_of[cfg]
                 T = -(-M // bm) * -(-N // bn)
-                U = T * -(-K // 32)
+                U = T * -(-K // bk_of[cfg])
                 if -sk > U or U / -sk < 2.5 or -sk < T // 2:   # too few units per workgroup / more than 2 tiles per workgroup
                     continue
             def run(W):
