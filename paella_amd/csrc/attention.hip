@@ -173,6 +173,173 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Large query counts (>= 256 queries per sample: 512 px grids and up, BASELINE configs 3-5 where attention is up to ~40 % of a
+// block's FLOPs): one workgroup = 64 queries of one (sample, head); its 4 waves own 16 queries each and SHARE the K/V tiles, which
+// are fetched from global memory ONCE per workgroup with coalesced 16-byte loads and staged in LDS (32 keys per stage, two stages,
+// register-prefetched: the loads of tile t+1 fly while tile t multiplies).
+//   K tile  [32][D + 4]: the K.Q^T fragment of a lane is 16 contiguous bytes of one key row -> ds_read_b128; the row pitch of
+//           D/4 + 1 (odd) 16-byte slots puts the 16 rows of a lane group on 16 different slots: conflict-free.
+//   V tile  [32][D + 4]: the V^T.P^T fragment of a lane is V[key = 4*kq + e][d = 16*j + r16] -> ds_read_b32; lanes r16 sweep 16
+//           consecutive banks and 4*(D + 4) mod 32 = 16 puts kq = 0 / 1 on disjoint halves: conflict-free.
+// Same arithmetic in the same order as the register-fed kernel above (16-key steps walked in key order per wave): results are
+// bit-identical to it.
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(256) void attention_lds_kernel(AttnArgs args) {
+    constexpr int D = DT * 16, D4 = D / 4;
+    constexpr int KTILE = 32;                 // keys per LDS stage
+    constexpr int PITCH = D + 4;              // floats per LDS row
+    constexpr int STAGE = 2 * KTILE * PITCH;  // K tile + V tile
+    constexpr int NITEM = KTILE * D4;         // float4 items per tensor per stage
+    constexpr int NL = (NITEM + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+
+    // scalar copies of the argument fields: lambdas that capture the argument STRUCT by reference make hipcc spill it to scratch
+    const int Lq = args.Lq, Lself = args.Lself, Lcond = args.Lcond, ld_self = args.ld_self, ld_cond = args.ld_cond, ldq = args.ldq, ldo = args.ldo;
+    const int n_kw = args.n_kw;
+    const float scale = args.scale;
+    const float* const key_weights = args.key_weights;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q0 = (blockIdx.x * 4 + wave) * 16;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int Lk = Lself + Lcond;
+    const int ntiles = (Lk + KTILE - 1) / KTILE;
+
+    f32x4 qf[DT];
+    {
+        const int q = min(q0 + r16, Lq - 1);  // rows past Lq are clamped; their outputs are not stored
+        const float* qp = args.q + ((size_t)b * Lq + q) * ldq + h * D + kq * 4;
+#pragma unroll
+        for (int j = 0; j < DT; ++j) qf[j] = *reinterpret_cast<const f32x4*>(qp + j * 16);
+    }
+    const float* ks_base = Lself ? args.k_self + (size_t)b * Lself * ld_self + h * D : nullptr;
+    const float* vs_base = Lself ? args.v_self + (size_t)b * Lself * ld_self + h * D : nullptr;
+    const float* kc_base = Lcond ? args.k_cond + (size_t)b * Lcond * ld_cond + h * D : nullptr;
+    const float* vc_base = Lcond ? args.v_cond + (size_t)b * Lcond * ld_cond + h * D : nullptr;
+
+    // staging: item = (key, c4) of the K tile and the same item of the V tile; loads are unconditional from clamped rows (masked
+    // keys get score -inf below).  K and V go through separate, fully unrolled loops: a run-time K/V selector makes hipcc build a
+    // pointer table in scratch.
+    f32x4 stk[NL], stv[NL];
+    auto load_tile = [&](int kt) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int idx = min(tid + i * 256, NITEM - 1);
+            const int key_in = idx / D4, c4 = idx - key_in * D4;
+            const int key = min(kt * KTILE + key_in, Lk - 1);
+            const bool self = key < Lself;
+            const size_t off = self ? (size_t)key * ld_self : (size_t)(key - Lself) * ld_cond;
+            stk[i] = *reinterpret_cast<const f32x4*>((self ? ks_base : kc_base) + off + c4 * 4);
+            stv[i] = *reinterpret_cast<const f32x4*>((self ? vs_base : vc_base) + off + c4 * 4);
+        }
+    };
+    auto store_tile = [&](int slot) __attribute__((always_inline)) {
+        float* base = smem + slot * STAGE;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int idx = tid + i * 256;
+            if (NL * 256 == NITEM || idx < NITEM) {
+                const int key_in = idx / D4, c4 = idx - key_in * D4;
+                *reinterpret_cast<f32x4*>(base + key_in * PITCH + c4 * 4) = stk[i];
+                *reinterpret_cast<f32x4*>(base + KTILE * PITCH + key_in * PITCH + c4 * 4) = stv[i];
+            }
+        }
+    };
+
+    f32x4 oacc[DT];
+#pragma unroll
+    for (int j = 0; j < DT; ++j) oacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+
+    auto process16 = [&](int key0, const float* Ks, const float* Vs) __attribute__((always_inline)) {  // 16 keys starting at key0; Ks / Vs = this sub-tile's rows
+        f32x4 kf[DT];
+        const float* kp = Ks + r16 * PITCH + kq * 4;
+#pragma unroll
+        for (int j = 0; j < DT; ++j) kf[j] = *reinterpret_cast<const f32x4*>(kp + j * 16);
+        f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < DT; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[j][e], qf[j][e], s, 0, 0, 0);
+        float vf[DT][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float* vp = Vs + (kq * 4 + e) * PITCH + r16;
+#pragma unroll
+            for (int j = 0; j < DT; ++j) vf[j][e] = vp[j * 16];
+        }
+        float p[4];
+        float mt = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = key0 + kq * 4 + r;
+            p[r] = key < Lk ? s[r] * scale : -INFINITY;
+            mt = fmaxf(mt, p[r]);
+        }
+        mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float m_new = fmaxf(m_run, mt);
+        const float alpha = expf(m_run - m_new);  // first tile: exp(-inf) = 0
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            p[r] = expf(p[r] - m_new);  // masked keys: exp(-inf) = 0, which also zeroes their (clamped) V rows
+            psum += p[r];
+        }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+        if (key_weights) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int wi = key0 + kq * 4 + r - (Lk - n_kw);
+                const float wv = key_weights[min(max(wi, 0), n_kw - 1)];
+                if (wi >= 0 && wi < n_kw) p[r] *= wv;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < DT; ++j) {
+            oacc[j] *= alpha;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) oacc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[j][e], p[e], oacc[j], 0, 0, 0);
+        }
+    };
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int slot = kt & 1;
+        load_tile(min(kt + 1, ntiles - 1));  // the last iteration re-reads its own tile (L1/L2 hit, never consumed)
+        __builtin_amdgcn_sched_barrier(0);
+        const float* Ks = smem + slot * STAGE;
+        const float* Vs = Ks + KTILE * PITCH;
+#pragma unroll
+        for (int sub = 0; sub < KTILE / 16; ++sub)
+            if (kt * KTILE + sub * 16 < Lk)  // workgroup-uniform: skip a fully masked half tile
+                process16(kt * KTILE + sub * 16, Ks + sub * 16 * PITCH, Vs + sub * 16 * PITCH);
+        __builtin_amdgcn_sched_barrier(0);
+        store_tile(slot ^ 1);
+        __syncthreads();
+    }
+    float l = l_run;
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    const int q = q0 + r16;
+    if (q < Lq) {
+        float* op = args.out + ((size_t)b * Lq + q) * ldo + h * D + kq * 4;
+#pragma unroll
+        for (int j = 0; j < DT; ++j) *reinterpret_cast<f32x4*>(op + j * 16) = oacc[j] * inv;
+    }
+}
+
+static int g_attn_variant = 0;  // test hook (test_hooks.h): 1 = force the register-fed kernel for large query counts too (A/B probes)
+extern "C" int paella_test_attention_variant(int v) { g_attn_variant = v; return PAELLA_OK; }
+
 int launch_attention(const AttnArgs& a, hipStream_t st) {
     if (a.B <= 0 || a.Lq <= 0) return PAELLA_OK;
     if (a.D % 16 || a.D > 128 || a.D <= 0) {
@@ -188,10 +355,12 @@ int launch_attention(const AttnArgs& a, hipStream_t st) {
     // small query counts (batch-1 sampling grids) are latency chains -> split keys over waves; large ones re-read K/V
     // once per workgroup, so give a workgroup 64 queries instead
     const bool ksplit = a.Lq < 256;
+    const bool lds = !ksplit && g_attn_variant != 1;
     dim3 grid(ksplit ? (a.Lq + 15) / 16 : (a.Lq + 63) / 64, a.nhead, a.B);
 #define ATT_CASE(n)                                                                                        \
     case n:                                                                                                \
         if (ksplit) hipLaunchKernelGGL((attention_kernel<n, true>), grid, dim3(256), 0, st, a);            \
+        else if (lds) hipLaunchKernelGGL((attention_lds_kernel<n>), grid, dim3(256), 0, st, a);            \
         else hipLaunchKernelGGL((attention_kernel<n, false>), grid, dim3(256), 0, st, a);                  \
         break;
     switch (a.D / 16) {

@@ -517,33 +517,6 @@ static inline long tiles_of_cfg(int c, int M, int N) {
     return (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
 }
 
-// Resident workgroups per CU of one instantiation (occupancy API, capped at 6: with ~106 SGPRs the hardware admits at most
-// floor(800 / 128) = 6 256-thread workgroups whatever the API says -- MI355X_MICROARCH.md "Residency").  A balanced-range launch
-// never uses more workgroups than fit at once: a second round would double the time of these ~20 us kernels.
-template <int WM, int WN, int TM, int TN, int PD, int APRO, int BK>
-static int occupancy_of() {
-    static int cached = -1;
-    if (cached < 0) {
-        int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_nt_kernel<WM, WN, TM, TN, PD, APRO, false, BK>, 64 * WM * WN, 0) != hipSuccess || n < 1) n = 2;
-        (void)hipGetLastError();
-        cached = n > 6 ? 6 : n;
-    }
-    return cached;
-}
-static int g_num_cus = 0;
-static int num_cus() {
-    if (g_num_cus <= 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) g_num_cus = prop.multiProcessorCount;
-        else g_num_cus = 256;
-        (void)hipGetLastError();
-    }
-    return g_num_cus;
-}
-static int gemm_occupancy(int cfg, int apro);
-
 // Tile / workgroup-count choice, fitted to tools/gemm_tune.py sweeps on MI355X (profiles/r02_gemm_tile_sweep.txt).
 // Returns the tile config and G (number of workgroups = number of contiguous unit ranges).  What the sweeps show:
 //  * >= 1024 tiles of 128x128: one tile per workgroup, 8 waves (cfg 10): 127-133 TFLOP/s at any K;
@@ -551,7 +524,8 @@ static int gemm_occupancy(int cfg, int apro);
 //    count: 1024x1280x5120 runs 125 us where one-tile-per-workgroup 64x64 tiles took 150);
 //  * 2.4-5 GFLOP: 128x64 tiles, 8 waves, one workgroup per CU (G = 256);
 //  * many small tiles with a short K (VQGAN full-resolution levels): 64x64 tiles, one each;
-//  * skinny batch-1 shapes: 32x32 tiles (5 workgroups per CU), ~10 K-steps per workgroup, at most 1280 workgroups -- every larger
+//  * skinny batch-1 shapes: 32x32 tiles, ~10 K-steps per workgroup, at most 1280 workgroups = 5 per CU, all resident at once
+//    (__launch_bounds__(256, 5) on that instantiation guarantees the registers for it) -- every larger
 //    tile lands within 5 % of it (24-27 us for 128x5120x1280): these launches are bound by ramp + combine, not by the tile.
 static void choose_config(int M, int N, int K, size_t slab_cap_bytes, int* cfg_out, unsigned* G_out) {
     const long ktiles = (K + 31) / 32;
@@ -670,7 +644,6 @@ static int launch_gemm_cfg_impl(const GemmArgs& g, int cfg, int splitk, void* ws
     const bool have_ws = ws && ws_bytes > kGemmTicketBytes;
     const size_t slab_cap = have_ws ? ws_bytes - kGemmTicketBytes : 0;
     unsigned G = 0;
-    const bool heuristic = cfg < 0;
     if (cfg < 0) {
         choose_config(g.M, g.N, g.K, slab_cap, &cfg, &G);
     } else {
@@ -690,10 +663,6 @@ static int launch_gemm_cfg_impl(const GemmArgs& g, int cfg, int splitk, void* ws
     p.U = (unsigned)U;
     if (G < 1) G = 1;
     if (G > p.U) G = p.U;
-    if (heuristic && G != (unsigned)T) {  // balanced ranges: every workgroup resident at once
-        const unsigned cap = (unsigned)(gemm_occupancy(cfg, g.a_scale ? 1 : (g.ln_stats ? 2 : 0)) * num_cus());
-        if (G > cap) G = cap >= (unsigned)T || T > 4ull * cap ? cap : (unsigned)T;
-    }
     if (g.ln_stats && p.tiles_m > 1) {
         // the LayerNorm-on-load variant computes its row statistics once per workgroup: keep every range inside one tile
         unsigned S = G / (unsigned)T;
@@ -785,24 +754,6 @@ int launch_gemm_tail(const GemmArgs& g, hipStream_t st) {
     LAUNCH_CHECK_RET();
     return PAELLA_OK;
 }
-
-#define OCC_CASE_BK(id, WMv, WNv, TMv, TNv, PDv, BKv) \
-    case id: return apro == 1 ? occupancy_of<WMv, WNv, TMv, TNv, PDv, 1, BKv>() : (apro == 2 ? occupancy_of<WMv, WNv, TMv, TNv, PDv, 2, BKv>() : occupancy_of<WMv, WNv, TMv, TNv, PDv, 0, BKv>());
-#define OCC_CASE(id, WMv, WNv, TMv, TNv, PDv) OCC_CASE_BK(id, WMv, WNv, TMv, TNv, PDv, 32)
-static int gemm_occupancy(int cfg, int apro) {
-    switch (cfg) {
-        OCC_CASE(0, 2, 2, 4, 4, 1) OCC_CASE(1, 2, 2, 4, 2, 2) OCC_CASE(2, 2, 2, 2, 2, 2) OCC_CASE(3, 2, 2, 2, 1, 2) OCC_CASE(4, 2, 2, 1, 2, 2)
-        OCC_CASE(5, 2, 2, 1, 1, 2) OCC_CASE(6, 1, 4, 1, 1, 2) OCC_CASE(7, 1, 4, 1, 2, 2) OCC_CASE(8, 1, 4, 2, 2, 2) OCC_CASE(9, 4, 2, 2, 4, 1)
-        OCC_CASE(10, 2, 4, 4, 2, 1) OCC_CASE(11, 4, 1, 2, 2, 2) OCC_CASE(12, 4, 1, 2, 4, 2) OCC_CASE(13, 4, 1, 1, 4, 2) OCC_CASE(14, 4, 2, 2, 2, 2)
-        OCC_CASE(15, 8, 1, 2, 2, 2) OCC_CASE(16, 8, 1, 2, 4, 1) OCC_CASE(17, 8, 1, 1, 4, 2) OCC_CASE(18, 2, 2, 2, 2, 1) OCC_CASE(19, 2, 2, 1, 1, 1)
-        OCC_CASE(20, 4, 1, 2, 4, 1) OCC_CASE(21, 4, 1, 1, 2, 2) OCC_CASE(22, 2, 2, 1, 4, 2) OCC_CASE(23, 1, 4, 2, 1, 2)
-        OCC_CASE_BK(24, 2, 2, 1, 1, 2, 64) OCC_CASE_BK(25, 2, 2, 1, 1, 1, 64) OCC_CASE_BK(26, 2, 2, 2, 2, 1, 64) OCC_CASE_BK(27, 4, 1, 2, 2, 1, 64)
-        OCC_CASE_BK(28, 2, 2, 1, 2, 1, 64) OCC_CASE_BK(29, 4, 2, 2, 2, 1, 64)
-        default: return 2;
-    }
-}
-#undef OCC_CASE
-#undef OCC_CASE_BK
 
 int launch_gemm(const GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t st) {
     return launch_gemm_cfg(g, -1, 1, ws, ws_bytes, st);

@@ -10,6 +10,8 @@ extern "C" {
 int paella_test_register_weight(const float* w, size_t numel, int on);
 /* launches n_launches dependent, nearly empty kernels (blocks x 256 threads touching n_elems floats): boundary floor */
 int paella_test_launch_chain(float* buf, int n_elems, int blocks, int n_launches, void* stream);
+/* 1 = run large-query-count attention on the register-fed kernel instead of the LDS-staged one (A/B probe, tools/attn_probe.py) */
+int paella_test_attention_variant(int v);
 #ifdef __cplusplus
 }
 #endif
