@@ -198,9 +198,13 @@ int paella_vqgan_decode(paella_vqgan* v, const float* latents, int B, int h, int
  * idx_out int64 [B,h,w], loss_out fp32 [1] = vq_loss + 0.25*commit_loss.  Any output pointer may be NULL. */
 int paella_vqgan_encode(paella_vqgan* v, const float* img, int B, int Hp, int Wp, float* qe_out, float* x_out,
                         int64_t* idx_out, float* loss_out, void* ws, size_t ws_bytes, void* stream);
-/* VectorQuantize.forward(x, dim=-1)[-1] on rows [rows, c_latent] (src_distributed/train.py:156) */
+/* VectorQuantize.forward on rows [rows, c_latent] (src/vqgan.py:94; src_distributed/train.py:156): nearest codebook row per
+ * input row -> idx_out int64 [rows], qe_out fp32 [rows, c_latent] (optional), mse_out fp32 [1] = mean((qe - x)^2) (optional;
+ * the stand-in's vq_loss == commit_loss). */
 int paella_vqgan_quantize_rows(paella_vqgan* v, const float* x, int64_t rows, int64_t* idx_out, float* qe_out,
-                               void* stream);
+                               float* mse_out, void* stream);
+/* VectorQuantize.idx2vq (src/vqgan.py:104): out fp32 [rows, c_latent] = codebook[idx] */
+int paella_vqgan_lookup_rows(paella_vqgan* v, const int64_t* idx, int64_t rows, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Single-op entry points (used by the parity tests and the kernel micro-benchmarks)

@@ -12,8 +12,8 @@
 //    [rows][32] floats with the 16-byte column slot XOR-swizzled by (row & 7): the staging ds_write_b128 and the
 //    fragment ds_read_b128 are conflict-free.
 //  * ONE work decomposition for every shape ("stream-K"): the launch's work is the sequence of U = tiles x K-steps
-//    units (tile-major, K-step minor); workgroup g of G owns the contiguous range [g*U/G, (g+1)*U/G) and walks it as
-//    ONE prefetch stream, flushing its accumulators whenever the range leaves a tile.
+//    units (tile-major, K-step minor); workgroup g of G owns a contiguous range of floor(U/G) or ceil(U/G) units and walks it
+//    as ONE prefetch stream, flushing its accumulators whenever the range leaves a tile.
 //      - G = tiles           : classic data-parallel (every workgroup one whole tile), large problems;
 //      - G = tiles * S       : classic split-K;
 //      - any other G         : balanced ranges for skinny problems (batch-1 sampling: M = 32..512 rows against
@@ -37,9 +37,17 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct SkPlan {
     int tiles_m, tiles_n;  // tile grid
-    int KT;                // K steps (of 32) per tile
+    int KT;                // K steps per tile
     unsigned U;            // tiles_m * tiles_n * KT work units
+    unsigned q, r;         // U = G*q + r: workgroup g owns [g*q + min(g, r), +q + (g < r)) -- 32-bit arithmetic only on the device
 };
+
+// first unit of workgroup g / the workgroup that owns unit x (inverse of the above)
+__device__ __forceinline__ unsigned sk_start(const SkPlan& p, unsigned g) { return g * p.q + min(g, p.r); }
+__device__ __forceinline__ unsigned sk_owner(const SkPlan& p, unsigned x) {
+    const unsigned big = p.r * (p.q + 1);  // units covered by the r workgroups that own q + 1 units
+    return x < big ? x / (p.q + 1) : p.r + (x - big) / p.q;
+}
 
 template <int WM, int WN, int TM, int TN, int PD, int APRO, bool TAIL = false, int BK = 32>  // BK: K step (32 or 64 floats per LDS row); APRO: 0 none, 1 GRN scale/shift, 2 LayerNorm from row statistics; TAIL: fused sampling tail (head GEMM)
 // The 32x32 tile is the batch-1 workhorse and wants 5 workgroups per CU (1280 resident): ask for <= 96 VGPRs there (the few
@@ -69,9 +77,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 &
         const unsigned xcd = gid & 7, idx = gid >> 3;
         gid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const unsigned u0 = (unsigned)(((unsigned long long)gid * p.U) / G);
-    const unsigned u1 = (unsigned)(((unsigned long long)(gid + 1) * p.U) / G);
-    const int n = (int)(u1 - u0);
+    const unsigned u0 = sk_start(p, gid);
+    const int n = (int)(p.q + (gid < p.r ? 1u : 0u));
     if (n <= 0) return;  // host keeps G <= U, so every workgroup owns at least one unit
     const int KT = p.KT;
 
@@ -368,15 +375,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 &
             unsigned* sflag = reinterpret_cast<unsigned*>(smem + 2 * TILE_FLOATS);
             if (tid == 0) sflag[0] = __hip_atomic_fetch_add(tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
-            // the workgroups whose ranges intersect this tile's units [tb, tb + KT): start(g) = floor(g*U/G) is strictly increasing
-            const unsigned long long tb = (unsigned long long)tile * (unsigned)KT;
-            const unsigned g_first = (unsigned)(((tb + 1) * G - 1) / p.U);
-            const unsigned g_last = (unsigned)(((tb + (unsigned)KT) * G - 1) / p.U);
+            // the workgroups whose ranges intersect this tile's units [tb, tb + KT)
+            const unsigned tb = (unsigned)tile * (unsigned)KT;
+            const unsigned g_first = sk_owner(p, tb);
+            const unsigned g_last = sk_owner(p, tb + (unsigned)KT - 1u);
             finish = sflag[0] == g_last - g_first;
             if (finish) {
                 if (tid == 0) __hip_atomic_store(tickets + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
-                const unsigned long long start_first = ((unsigned long long)g_first * p.U) / G;
-                const unsigned off_first = (2u * g_first + (start_first < tb ? 1u : 0u)) * SLOT_BYTES;  // g_first came from an earlier tile -> its tail slot
+                const unsigned off_first = (2u * g_first + (sk_start(p, g_first) < tb ? 1u : 0u)) * SLOT_BYTES;  // g_first came from an earlier tile -> its tail slot
                 const unsigned wbase = (unsigned)(wave * FR * 4);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
@@ -679,6 +685,8 @@ static int launch_gemm_cfg_impl(const GemmArgs& g, int cfg, int splitk, void* ws
         }
         slab_bytes = (unsigned)need;
     }
+    p.q = p.U / G;
+    p.r = p.U % G;
     unsigned* tickets = have_ws ? reinterpret_cast<unsigned*>(ws) : nullptr;
     float* slabs = have_ws ? reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + kGemmTicketBytes) : nullptr;
 #define GEMM_CASE(id, WMv, WNv, TMv, TNv, PDv) \
@@ -749,6 +757,8 @@ int launch_gemm_tail(const GemmArgs& g, hipStream_t st) {
     const unsigned long long T = (unsigned long long)p.tiles_m * p.tiles_n;
     if (T * (unsigned long long)p.KT >= (1ull << 31)) { paella_set_error("gemm_tail: problem too large"); return PAELLA_ERR_ARG; }
     p.U = (unsigned)(T * p.KT);
+    p.q = (unsigned)p.KT;  // one whole tile per workgroup
+    p.r = 0;
     if (cfg == 9) hipLaunchKernelGGL((gemm_nt_kernel<4, 2, 2, 4, 1, 0, true>), dim3((unsigned)T), dim3(512), 0, st, g, p, (float*)nullptr, (unsigned*)nullptr, 0u);
     else hipLaunchKernelGGL((gemm_nt_kernel<2, 2, 2, 2, 2, 0, true>), dim3((unsigned)T), dim3(256), 0, st, g, p, (float*)nullptr, (unsigned*)nullptr, 0u);
     LAUNCH_CHECK_RET();

@@ -334,8 +334,8 @@ extern "C" int paella_vqgan_decode(paella_vqgan* v, const float* latents, int B,
     return vq_run_decoder(v, f, B, h, w, img_out, st);
 }
 
-__global__ __launch_bounds__(256) void vq_loss_kernel(const float* __restrict__ qe, const float* __restrict__ x, int64_t n, float* __restrict__ out) {
-    // single workgroup, fixed-order reduction: loss = 1.25 * mean((qe - x)^2)   (vq_loss + 0.25 * commit_loss)
+__global__ __launch_bounds__(256) void vq_loss_kernel(const float* __restrict__ qe, const float* __restrict__ x, int64_t n, float* __restrict__ out, int combined) {
+    // single workgroup, fixed-order reduction: mse = mean((qe - x)^2); combined: out = vq_loss + 0.25 * commit_loss = 1.25 * mse
     __shared__ double red[256];
     double s = 0.0;
     for (int64_t i = threadIdx.x; i < n; i += 256) {
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256) void vq_loss_kernel(const float* __restrict__ 
     }
     if (threadIdx.x == 0) {
         const float mse = (float)(red[0] / (double)n);
-        out[0] = mse + mse * 0.25f;
+        out[0] = combined ? mse + mse * 0.25f : mse;
     }
 }
 
@@ -403,14 +403,27 @@ extern "C" int paella_vqgan_encode(paella_vqgan* v, const float* img, int B, int
     if (qe_out) RET_IF(launch_nhwc_to_nchw(f.qe, qe_out, B, h * w, cl, v->cfg.scale_factor, 1, st));
     if (x_out) RET_IF(launch_nhwc_to_nchw(f.lat, x_out, B, h * w, cl, v->cfg.scale_factor, 1, st));
     if (loss_out) {
-        hipLaunchKernelGGL(vq_loss_kernel, dim3(1), dim3(256), 0, st, f.qe, f.lat, rows * cl, loss_out);
+        hipLaunchKernelGGL(vq_loss_kernel, dim3(1), dim3(256), 0, st, f.qe, f.lat, rows * cl, loss_out, 1);
         LAUNCH_CHECK_RET();
     }
     return PAELLA_OK;
 }
 
-extern "C" int paella_vqgan_quantize_rows(paella_vqgan* v, const float* x, int64_t rows, int64_t* idx_out, float* qe_out, void* stream) {
+extern "C" int paella_vqgan_quantize_rows(paella_vqgan* v, const float* x, int64_t rows, int64_t* idx_out, float* qe_out, float* mse_out,
+                                          void* stream) {
     if (!v || !v->finalized) { paella_set_error("VQGAN not finalized"); return PAELLA_ERR_STATE; }
-    if (!x || !idx_out) { paella_set_error("null argument"); return PAELLA_ERR_ARG; }
-    return launch_vq_nearest(x, VT(v, "vquantizer.codebook.weight"), idx_out, qe_out, rows, v->cfg.c_latent, v->cfg.codebook_size, (hipStream_t)stream);
+    if (!x || !idx_out || (mse_out && !qe_out)) { paella_set_error("null argument"); return PAELLA_ERR_ARG; }
+    RET_IF(launch_vq_nearest(x, VT(v, "vquantizer.codebook.weight"), idx_out, qe_out, rows, v->cfg.c_latent, v->cfg.codebook_size, (hipStream_t)stream));
+    if (mse_out && rows > 0) {
+        hipLaunchKernelGGL(vq_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, qe_out, x, rows * v->cfg.c_latent, mse_out, 0);
+        LAUNCH_CHECK_RET();
+    }
+    return PAELLA_OK;
+}
+
+// VectorQuantize.idx2vq (used at src/vqgan.py:104): codebook rows for a flat index list, out fp32 [rows, c_latent]
+extern "C" int paella_vqgan_lookup_rows(paella_vqgan* v, const int64_t* idx, int64_t rows, float* out, void* stream) {
+    if (!v || !v->finalized) { paella_set_error("VQGAN not finalized"); return PAELLA_ERR_STATE; }
+    if (!idx || !out) { paella_set_error("null argument"); return PAELLA_ERR_ARG; }
+    return launch_codebook_gather(idx, VT(v, "vquantizer.codebook.weight"), out, rows, v->cfg.c_latent, v->cfg.codebook_size, 1.0f, (hipStream_t)stream);
 }

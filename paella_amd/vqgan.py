@@ -45,11 +45,10 @@ class VectorQuantize(nn.Module):
         if dim != -1:
             x = x.movedim(dim, -1)
         flat = x.contiguous().view(-1, x.size(-1)).float().contiguous()
-        idx, qe = owner._quantize_rows(flat)
+        idx, qe, mse = owner._quantize_rows(flat, get_losses)
         vq_loss = commit_loss = None
         if get_losses:
-            mse = (qe - flat).pow(2).mean()
-            vq_loss, commit_loss = mse, mse.clone()
+            vq_loss, commit_loss = mse[0], mse[0].clone()
         z_q = qe.view(x.shape)
         if dim != -1:
             z_q = z_q.movedim(-1, dim)
@@ -162,19 +161,27 @@ class VQModel(nn.Module):
             self._ws = _lib.new_workspace(nbytes, dev)
         return self._ws
 
-    def _quantize_rows(self, flat):
+    def _quantize_rows(self, flat, with_mse=False):
         h = self._engine()
         dev = self._device()
         idx = torch.empty(flat.size(0), dtype=torch.int64, device=dev)
         qe = torch.empty_like(flat)
+        mse = torch.empty(1, dtype=torch.float32, device=dev) if with_mse else None
         with torch.cuda.device(dev):
-            _lib.check(_lib.load().paella_vqgan_quantize_rows(h, _lib.ptr(flat), flat.size(0), _lib.ptr(idx), _lib.ptr(qe),
+            _lib.check(_lib.load().paella_vqgan_quantize_rows(h, _lib.ptr(flat), flat.size(0), _lib.ptr(idx), _lib.ptr(qe), _lib.ptr(mse),
                                                               _lib.stream_ptr(dev)))
-        return idx, qe
+        return idx, qe, mse
 
     def _gather_rows(self, idx_flat):
-        # embedding lookup = torch indexing of the codebook parameter (memory plumbing, no arithmetic)
-        return self.vquantizer.codebook.weight.detach()[idx_flat]
+        h = self._engine()
+        dev = self._device()
+        if not idx_flat.is_cuda or idx_flat.dtype != torch.int64:
+            raise ValueError("indices must be an int64 HIP tensor")
+        idx_flat = idx_flat.contiguous()
+        out = torch.empty(idx_flat.numel(), self.c_latent, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().paella_vqgan_lookup_rows(h, _lib.ptr(idx_flat), idx_flat.numel(), _lib.ptr(out), _lib.stream_ptr(dev)))
+        return out
 
     # ------------------------------------------------------------------ reference surface
     def encode(self, x):

@@ -61,3 +61,74 @@ def test_full_size_f8_decode_vs_oracle(built_lib):
     diff = (got - ref).abs().max().item()
     print("f8 decode: output std %.3f max|diff| %.3e" % (ref.std().item(), diff))
     assert diff <= 2e-4 * max(1.0, ref.abs().max().item())
+
+
+def test_full_size_encode_vs_oracle(built_lib):
+    """VQModel.encode at the released size (f8: levels=3, c_hidden=384) on a 256x256 image against the CPU oracle
+    (src/vqgan.py:91-95): pre-quantisation latents to 5e-5, token indices exact except at nearest-code near-ties (counted)."""
+    vc = G.VQ_F8
+    v = paella_amd.VQModel(**vc)
+    sd = weights_for(v, vc["bottleneck_blocks"])
+    v = v.to(DEV)
+    g = torch.Generator().manual_seed(17)
+    img = torch.rand(1, 3, 256, 256, generator=g)
+    with torch.no_grad():
+        oq, olat, oidx, oloss = O.vq_encode(sd, vc, img)
+    qe, lat, idx, loss = v.encode(img.to(DEV))
+    np.testing.assert_allclose(lat.cpu().numpy(), olat.numpy(), atol=5e-5)
+    mism = idx.cpu() != oidx
+    rows = (olat * vc["scale_factor"]).permute(0, 2, 3, 1).reshape(-1, vc["c_latent"]).double()
+    d = torch.cdist(rows, sd["vquantizer.codebook.weight"].double()).pow(2)
+    top = d.topk(2, dim=1, largest=False).values
+    near = ((top[:, 1] - top[:, 0]) < 1e-5).view(mism.shape)
+    print("f8 encode 256 px: %d / %d tokens differ, all at nearest-code near-ties: %s" % (int(mism.sum()), mism.numel(), not bool((mism & ~near).any())))
+    assert not (mism & ~near).any()
+    if not mism.any():
+        np.testing.assert_allclose(qe.cpu().numpy(), oq.numpy(), atol=1e-6)
+        np.testing.assert_allclose(float(loss), float(oloss), rtol=1e-3)
+    # VectorQuantize surface: losses and idx2vq run in the HIP library too
+    zq, (vq_loss, commit), ids = v.vquantizer(lat * vc["scale_factor"], dim=1)
+    assert torch.equal(ids, idx) and abs(float(vq_loss) * 1.25 - float(loss)) <= 1e-4 * max(1.0, float(loss))
+    np.testing.assert_allclose(v.vquantizer.idx2vq(idx, dim=1).cpu().numpy(), zq.cpu().numpy(), atol=0)
+
+
+def test_inpaint_composition_vs_oracle(built_lib):
+    """paella_amd.inpaint against the oracle's composition of the same reference pieces: vq_encode -> add_noise with
+    the user mask -> sample(init_x, t_start < 1) with explicit noise -> vq_decode_indices, on the tiny configs."""
+    cfg = G.UNET_TINY
+    vc = dict(G.VQ_TINY_F8, codebook_size=cfg["num_labels"])
+    m = paella_amd.Paella(**cfg)
+    sd = weights_for(m, sum(cfg["blocks"]))
+    m = m.to(DEV)
+    vq = paella_amd.VQModel(**vc)
+    vsd = weights_for(vq, vc["bottleneck_blocks"])
+    vq = vq.to(DEV)
+    from tests.helpers import cond_for, to_dev
+    g = torch.Generator().manual_seed(4)
+    B, steps, t_start = 2, 4, 0.6
+    img = torch.rand(B, 3, 128, 128, generator=g)  # f8 -> 16x16 tokens
+    c, u = cond_for(cfg, B, 3, 0, 1), cond_for(cfg, B, 3, 0, 2)
+    mask = torch.zeros(B, 16, 16, dtype=torch.int64)
+    mask[:, 4:12, 4:12] = 1
+    random_x = torch.randint(0, cfg["num_labels"], (B, 16, 16), generator=g)
+    noise = O.replay_torch_noise(5, (B, 16, 16), cfg["num_labels"], steps, steps - 1)
+    # oracle composition
+    with torch.no_grad():
+        _, _, otok, _ = O.vq_encode(vsd, vc, img)
+        noised, _ = O.add_noise(otok, torch.full((B,), t_start), cfg["num_labels"], mask=mask, random_x=random_x)
+        t_list = [float(v) for v in torch.linspace(t_start, 0.0, steps + 1)]
+        temps = [float(v) for v in torch.linspace(0.7, 0.3, steps)]
+        sched = torch.linspace(8.0, 8.0, steps)
+        cfgs = [(float(sched[i]), float(1 - sched[i])) for i in range(steps)]
+        fwd = lambda tk, rr, **inp: O.unet_forward(sd, cfg, tk, rr, **inp)
+        osamp, _ = O.sample(fwd, cfg["num_labels"], c, u, (B, 16, 16), init_x=noised, steps=steps, renoise_steps=steps - 1, temperatures=temps,
+                            cfgs=cfgs, t_list=t_list, noise=noise)
+        oimg = O.vq_decode_indices(vsd, vc, osamp)
+    toks, out = paella_amd.inpaint(m, vq, img.to(DEV), mask, to_dev(c, DEV), to_dev(u, DEV), steps=steps, t_start=t_start, keep_known=False,
+                                   random_x=random_x.to(DEV), noise=noise)
+    enc_same = torch.equal(vq.encode(img.to(DEV))[2].cpu(), otok)
+    same = int((toks.cpu() == osamp).sum())
+    print("inpaint vs oracle composition: encode tokens identical %s, %d / %d sampled tokens identical" % (enc_same, same, osamp.numel()))
+    assert enc_same
+    assert same == osamp.numel()
+    np.testing.assert_allclose(out.cpu().numpy(), oimg.numpy(), atol=1e-4)

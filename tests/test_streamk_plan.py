@@ -1,6 +1,6 @@
 """CPU: the stream-K work decomposition of paella_amd/csrc/gemm.hip, restated in Python and checked exhaustively on small cases.
 
-The kernel gives workgroup g of G the unit range [g*U/G, (g+1)*U/G) of the U = tiles*KT (tile, K-step) units.  Partial tiles are
+The kernel gives workgroup g of G the unit range [g*q + min(g, r), +q + (g < r)) (U = G*q + r) of the U = tiles*KT (tile, K-step) units.  Partial tiles are
 published to slab slot 2g ("head": the segment starts the workgroup's range) or 2g+1 (a later, necessarily last, segment) and the
 last arriver recomputes from (tile, G, U) alone which workgroups contributed and in which slot.  This test proves, for every
 (tiles, KT, G) in a grid, that reader and writers agree: same part set, same slots, ticket target = parts - 1, every K step of
@@ -11,7 +11,14 @@ import pytest
 
 
 def start(g, U, G):
-    return (g * U) // G
+    q, r = divmod(U, G)  # workgroup g owns q + (g < r) units
+    return g * q + min(g, r)
+
+
+def owner(x, U, G):
+    q, r = divmod(U, G)
+    big = r * (q + 1)
+    return x // (q + 1) if x < big else r + (x - big) // q
 
 
 def writer_segments(g, U, G, KT):
@@ -34,8 +41,8 @@ def writer_segments(g, U, G, KT):
 def reader_parts(tile, U, G, KT):
     """What the last arriver of `tile` computes: [(workgroup, slot)] in summation order."""
     tb = tile * KT
-    g_first = ((tb + 1) * G - 1) // U
-    g_last = ((tb + KT) * G - 1) // U
+    g_first = owner(tb, U, G)
+    g_last = owner(tb + KT - 1, U, G)
     parts = []
     for gp in range(g_first, g_last + 1):
         tail = gp == g_first and start(g_first, U, G) < tb
