@@ -31,6 +31,7 @@
 #include "gemm_device.h"
 #include "philox.h"
 #include <stdio.h>
+#include <type_traits>
 #include <vector>
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -111,24 +112,33 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 &
     Stage R[PD];
 
     // ---- load cursor ----
+    // Operands are read through buffer descriptors: per-thread 32-bit byte offsets (recomputed only when the cursor enters a new
+    // tile) + ONE uniform K offset in an SGPR per unit -> no vector address arithmetic in the unit loop.  Reads past the end of a
+    // buffer return 0 (hardware range check), so only the M / N clamps remain; the K tail is masked when the tile is staged.
     int ltile = (int)(u0 / (unsigned)KT);
     int lkt = (int)(u0 - (unsigned)ltile * (unsigned)KT);
-    const float* aptr[LA];
-    const float* sptr[APRO == 1 ? LA : 1];
-    const float* bptr[LB];
+    auto rsrc_of = [](const float* ptr, size_t bytes) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ptr), 0, (int)(bytes > 0xffffffffull ? 0xffffffffull : bytes), 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t rsrcA = rsrc_of(g.A, ((size_t)(g.M - 1) * g.lda + g.K) * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rsrcW = rsrc_of(g.W, ((size_t)(g.N - 1) * g.ldw + g.K) * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rsrcS = rsrc_of(APRO == 1 ? g.a_scale : g.A,
+                                                 APRO == 1 ? (size_t)((g.M - 1) / g.a_rows_per_sample + 1) * g.K * sizeof(float) : 16);
+    const __amdgpu_buffer_rsrc_t rsrcT = rsrc_of(APRO == 1 ? g.a_shift : g.A, APRO == 1 ? (size_t)g.K * sizeof(float) : 16);
+    unsigned aoff[LA], soff[APRO == 1 ? LA : 1], boff[LB];
     float ln_mu[APRO == 2 ? LA : 1], ln_rs[APRO == 2 ? LA : 1];
-    auto set_tile = [&](int tile) {
+    auto set_tile = [&](int tile) __attribute__((always_inline)) {
         const int tile_m = tile % p.tiles_m;  // m fastest: consecutive tiles share the weight panel
         const int tile_n = tile / p.tiles_m;
         const int m0 = tile_m * BM, n0 = tile_n * BN;
 #pragma unroll
         for (int i = 0; i < LA; ++i) {
             const int gmc = min(m0 + ldrow + i * RP, g.M - 1);
-            aptr[i] = g.A + (size_t)gmc * g.lda;
-            if (APRO == 1) sptr[i] = g.a_scale + (size_t)(gmc / g.a_rows_per_sample) * g.K;
+            aoff[i] = ((unsigned)gmc * (unsigned)g.lda + (unsigned)(ldc4 * 4)) * 4u;
+            if (APRO == 1) soff[i] = ((unsigned)(gmc / g.a_rows_per_sample) * (unsigned)g.K + (unsigned)(ldc4 * 4)) * 4u;
         }
 #pragma unroll
-        for (int i = 0; i < LB; ++i) bptr[i] = g.W + (size_t)min(n0 + ldrow + i * RP, g.N - 1) * g.ldw;
+        for (int i = 0; i < LB; ++i) boff[i] = ((unsigned)min(n0 + ldrow + i * RP, g.N - 1) * (unsigned)g.ldw + (unsigned)(ldc4 * 4)) * 4u;
     };
     set_tile(ltile);
     if (APRO == 2) {
@@ -151,19 +161,19 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 &
         }
     }
 
-    auto load_unit = [&](Stage& r) {  // loads the unit under the load cursor
-        const int kc = min(lkt * BK + ldc4 * 4, g.K - 4);
+    auto load_unit = [&](Stage& r) __attribute__((always_inline)) {  // loads the unit under the load cursor
+        const int kofs = lkt * (BK * 4);  // uniform byte offset of this K step -> the loads' SGPR offset
 #pragma unroll
         for (int i = 0; i < LA; ++i) {
-            r.a[i] = *reinterpret_cast<const f32x4*>(aptr[i] + kc);
-            if (APRO == 1) r.s[i] = *reinterpret_cast<const f32x4*>(sptr[i] + kc);
+            r.a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcA, aoff[i], kofs, 0));
+            if (APRO == 1) r.s[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcS, soff[i], kofs, 0));
         }
-        if (APRO == 1) r.t = *reinterpret_cast<const f32x4*>(g.a_shift + kc);
+        if (APRO == 1) r.t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcT, (unsigned)(ldc4 * 16), kofs, 0));
 #pragma unroll
-        for (int i = 0; i < LB; ++i) r.b[i] = *reinterpret_cast<const f32x4*>(bptr[i] + kc);
+        for (int i = 0; i < LB; ++i) r.b[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcW, boff[i], kofs, 0));
         r.kok = lkt * BK + ldc4 * 4 < g.K;
     };
-    auto store_unit = [&](const Stage& r, int slot) {
+    auto store_unit = [&](const Stage& r, int slot) __attribute__((always_inline)) {
         float* As = smem + slot * TILE_FLOATS;
         float* Bs = As + BM * BK;
 #pragma unroll
@@ -185,7 +195,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 &
     // (v_mfma_f32_16x16x4_f32: 32-cycle issue, 40-cycle dependent latency).
     constexpr bool DUAL = (TM * TN == 1);
     f32x4 acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto compute = [&](int slot) {
+    auto compute = [&](int slot) __attribute__((always_inline)) {
         const float* As = smem + slot * TILE_FLOATS;
         const float* Bs = As + BM * BK;
         // small wave tiles and the 8-wave 128x128 configs: all fragment reads of the tile up front (one exposed LDS latency
@@ -414,7 +424,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 &
     // ---- the unit stream ----
     // invariant at the top of unit i: unit i is in LDS[slot]; R[(i+1)%PD .. (i+PD-1)%PD] hold units i+1..i+PD-1; R[i%PD] is free
     int loaded = 0;  // units fetched so far; the load cursor stops on the range's last unit (re-reading it hits L1/L2)
-    auto fetch = [&](Stage& r) {
+    auto fetch = [&](Stage& r) __attribute__((always_inline)) {
         load_unit(r);
         if (++loaded < n && ++lkt == KT) {  // workgroup-uniform; never runs into the next workgroup's units
             lkt = 0;
@@ -433,32 +443,42 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 &
     int slot = 0;
     // one unit: `rf` is the free ring stage (gets the unit PD ahead), `rs` holds the next unit (goes to the other LDS stage).
     // One basic block per phase: the prefetch is pinned above the MFMA block (hipcc sinks it otherwise).
-    auto step = [&](Stage& rf, const Stage& rs) {
+    auto step = [&](Stage& rf, const Stage& rs, int sl) __attribute__((always_inline)) {
         fetch(rf);
         __builtin_amdgcn_sched_barrier(0);
-        compute(slot);
+        compute(sl);
         __builtin_amdgcn_sched_barrier(0);
-        store_unit(rs, slot ^ 1);
+        store_unit(rs, sl ^ 1);
         __syncthreads();
-        slot ^= 1;
     };
-    for (int i = 0; i < n;) {
-        const int seg_len = min(KT - ckt, n - i);
+    // A segment's units with COMPILE-TIME LDS stages and ring roles (immediate LDS offsets, statically indexed register stages):
+    // two instantiations, by the LDS stage the segment starts in.  A segment of odd length leaves the ring in phase 1, so it is
+    // re-based with ONE stage copy per segment.
+    auto run_segment = [&](auto s0_tag, int len) __attribute__((always_inline)) {
+        constexpr int S0 = decltype(s0_tag)::value;
+        int s = 0;
         if constexpr (PD == 1) {
-            for (int s = 0; s < seg_len; ++s) step(R[0], R[0]);
-        } else {
-            // ring roles are static inside the pair loop (runtime-indexed register arrays go to scratch); a segment of odd
-            // length leaves the ring in phase 1, so it is re-based with ONE stage copy per segment
-            int s = 0;
-            for (; s + 2 <= seg_len; s += 2) {
-                step(R[0], R[1]);
-                step(R[1], R[0]);
+            for (; s + 2 <= len; s += 2) {
+                step(R[0], R[0], S0);
+                step(R[0], R[0], S0 ^ 1);
             }
-            if (s < seg_len) {
-                step(R[0], R[1]);
+            if (s < len) step(R[0], R[0], S0);
+        } else {
+            for (; s + 2 <= len; s += 2) {
+                step(R[0], R[1], S0);
+                step(R[1], R[0], S0 ^ 1);
+            }
+            if (s < len) {
+                step(R[0], R[1], S0);
                 R[1] = R[0];
             }
         }
+    };
+    for (int i = 0; i < n;) {
+        const int seg_len = min(KT - ckt, n - i);
+        if (slot == 0) run_segment(std::integral_constant<int, 0>{}, seg_len);
+        else run_segment(std::integral_constant<int, 1>{}, seg_len);
+        slot ^= seg_len & 1;
         flush(ctile, ckt, ckt + seg_len, first_seg);
         first_seg = false;
         i += seg_len;
@@ -640,6 +660,10 @@ static int launch_gemm_cfg_impl(const GemmArgs& g, int cfg, int splitk, void* ws
     }
     if (g.ep.store_mode == STORE_D2S && (g.ep.sC & 3)) {
         paella_set_error("gemm: depth-to-space store needs channels %% 4 == 0");
+        return PAELLA_ERR_ARG;
+    }
+    if (((size_t)(g.M - 1) * g.lda + g.K) * sizeof(float) > 0xffffffffull || ((size_t)(g.N - 1) * g.ldw + g.K) * sizeof(float) > 0xffffffffull) {
+        paella_set_error("gemm: an operand of 4 GiB or more (M=%d lda=%d N=%d ldw=%d): split the rows -- operands are read through 32-bit buffer offsets", g.M, g.lda, g.N, g.ldw);
         return PAELLA_ERR_ARG;
     }
     if (cfg >= 96 && cfg < 99) return launch_gemm_bf16(g, cfg - 96, splitk, ws, ws_bytes, st);  // explicit bf16 tile (tests / tools)
