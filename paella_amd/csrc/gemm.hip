@@ -51,9 +51,10 @@ __device__ __forceinline__ unsigned sk_owner(const SkPlan& p, unsigned x) {
 }
 
 template <int WM, int WN, int TM, int TN, int PD, int APRO, bool TAIL = false, int BK = 32>  // BK: K step (32 or 64 floats per LDS row); APRO: 0 none, 1 GRN scale/shift, 2 LayerNorm from row statistics; TAIL: fused sampling tail (head GEMM)
-// The 32x32 tile is the batch-1 workhorse and wants 5 workgroups per CU (1280 resident): ask for <= 96 VGPRs there (the few
-// spills this costs the prologue variants sit in the flush path, never in the unit loop -- checked in the ISA).
-__global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 && PD == 2 && BK == 32) ? 5 : 1) void gemm_nt_kernel(GemmArgs g, SkPlan p, float* __restrict__ slabs,
+// The 32x32 tile is the batch-1 workhorse and wants 5 workgroups per CU (1280 resident): ask for <= 96 VGPRs there.  Not for the
+// GRN-prologue variant (two more staged operands per unit): forced under 96 registers it spills inside the unit loop (measured
+// 33 us instead of 25 for 128x1280x5120), so it runs 4 workgroups per CU and the heuristic gives it at most 1024 workgroups.
+__global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 && PD == 2 && BK == 32 && APRO != 1) ? 5 : 1) void gemm_nt_kernel(GemmArgs g, SkPlan p, float* __restrict__ slabs,
                                                                unsigned* __restrict__ tickets, unsigned slab_bytes) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
     constexpr int SL = BK / 4;     // 16-byte slots per LDS row; slot s of row r lives at s ^ (r & (SL - 1)): conflict-free ds_write_b128 / ds_read_b128
@@ -553,7 +554,7 @@ static inline long tiles_of_cfg(int c, int M, int N) {
 //  * skinny batch-1 shapes: 32x32 tiles, ~10 K-steps per workgroup, at most 1280 workgroups = 5 per CU, all resident at once
 //    (__launch_bounds__(256, 5) on that instantiation guarantees the registers for it) -- every larger
 //    tile lands within 5 % of it (24-27 us for 128x5120x1280): these launches are bound by ramp + combine, not by the tile.
-static void choose_config(int M, int N, int K, size_t slab_cap_bytes, int* cfg_out, unsigned* G_out) {
+static void choose_config(int M, int N, int K, int apro, size_t slab_cap_bytes, int* cfg_out, unsigned* G_out) {
     const long ktiles = (K + 31) / 32;
     const double macs = (double)M * N * K;
     const long T128 = tiles_of_cfg(10, M, N), T64 = tiles_of_cfg(18, M, N), T32 = tiles_of_cfg(5, M, N);
@@ -568,7 +569,8 @@ static void choose_config(int M, int N, int K, size_t slab_cap_bytes, int* cfg_o
         const long U = T32 * ktiles;
         G = U / 10;
         if (G < T32) G = T32;
-        if (G > 1280) G = 1280;
+        const long resident = apro == 1 ? 1024 : 1280;  // workgroups that fit at once (see the launch bounds above)
+        if (G > resident) G = resident;
     }
     const long T = tiles_of_cfg(cfg, M, N);
     const long U = T * ktiles;
@@ -675,7 +677,7 @@ static int launch_gemm_cfg_impl(const GemmArgs& g, int cfg, int splitk, void* ws
     const size_t slab_cap = have_ws ? ws_bytes - kGemmTicketBytes : 0;
     unsigned G = 0;
     if (cfg < 0) {
-        choose_config(g.M, g.N, g.K, slab_cap, &cfg, &G);
+        choose_config(g.M, g.N, g.K, g.a_scale ? 1 : (g.ln_stats ? 2 : 0), slab_cap, &cfg, &G);
     } else {
         if (cfg >= kNumCfgs) { paella_set_error("gemm: bad tile config %d", cfg); return PAELLA_ERR_ARG; }
         const long T = tiles_of_cfg(cfg, g.M, g.N);
