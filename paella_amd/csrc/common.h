@@ -83,6 +83,16 @@ struct FusedTail {
     int* part_idx;               // [M, tiles_n]
 };
 
+// Implicit-GEMM convolution (VQGAN k4 s2 p1 Conv2d / the 4 output phases of the k4 s2 p1 ConvTranspose2d, reference src/vqgan.py:59-61,
+// 81-85): the A operand is never materialised.  Row m = output position (b, yo, xo) on a [Ho, Wo] grid, K index = tap * C + c,
+// A[m][tap*C + c] = x[b][yo*stride + oy[tap]][xo*stride + ox[tap]][c] (0 outside the [Hi, Wi] input grid), x = GemmArgs::A in NHWC.
+// The gather happens in the GEMM's operand load (per-row offsets + a per-K-step tap offset); needs C % (K step) == 0.
+struct ConvGather {
+    int enabled;
+    int Hi, Wi, C, Ho, Wo, stride, ntaps;
+    int off[16];  // per tap: (oy << 16) | (ox & 0xffff)
+};
+
 struct GemmArgs {
     const float* A; int lda;   // [M, K] row-major
     const float* W; int ldw;   // [N, K] row-major (torch Linear layout)
@@ -99,6 +109,7 @@ struct GemmArgs {
     float ln_eps;
     Epilogue ep;
     FusedTail ft;              // used by launch_gemm_tail only
+    ConvGather cv;             // cv.enabled: A is an NHWC image gathered on the fly (lda unused, K == ntaps * C)
 };
 
 // Launchers (each returns PAELLA_OK or an error code; all work is enqueued on `stream`).

@@ -109,6 +109,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 &
         f32x4 t;
         f32x4 b[LB];
         bool kok;
+        bool ok[APRO == 3 ? LA : 1];  // implicit conv: the tap of this K step falls inside the input grid for row i
     };
     Stage R[PD];
 
@@ -121,12 +122,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 &
     auto rsrc_of = [](const float* ptr, size_t bytes) {
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ptr), 0, (int)(bytes > 0xffffffffull ? 0xffffffffull : bytes), 0x00020000);
     };
-    const __amdgpu_buffer_rsrc_t rsrcA = rsrc_of(g.A, ((size_t)(g.M - 1) * g.lda + g.K) * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rsrcA = rsrc_of(g.A, APRO == 3 ? (size_t)(g.M / (g.cv.Ho * g.cv.Wo)) * g.cv.Hi * g.cv.Wi * g.cv.C * sizeof(float)
+                                                             : ((size_t)(g.M - 1) * g.lda + g.K) * sizeof(float));
     const __amdgpu_buffer_rsrc_t rsrcW = rsrc_of(g.W, ((size_t)(g.N - 1) * g.ldw + g.K) * sizeof(float));
     const __amdgpu_buffer_rsrc_t rsrcS = rsrc_of(APRO == 1 ? g.a_scale : g.A,
                                                  APRO == 1 ? (size_t)((g.M - 1) / g.a_rows_per_sample + 1) * g.K * sizeof(float) : 16);
     const __amdgpu_buffer_rsrc_t rsrcT = rsrc_of(APRO == 1 ? g.a_shift : g.A, APRO == 1 ? (size_t)g.K * sizeof(float) : 16);
     unsigned aoff[LA], soff[APRO == 1 ? LA : 1], boff[LB];
+    int cy[APRO == 3 ? LA : 1], cx[APRO == 3 ? LA : 1];  // implicit conv: top-left input coordinate of row i (aoff[i] = image base position)
+    int ltap = 0, lc0 = 0;                                  // implicit conv: tap and channel offset of the load cursor's K step
     float ln_mu[APRO == 2 ? LA : 1], ln_rs[APRO == 2 ? LA : 1];
     auto set_tile = [&](int tile) __attribute__((always_inline)) {
         const int tile_m = tile % p.tiles_m;  // m fastest: consecutive tiles share the weight panel
@@ -135,13 +139,26 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 &
 #pragma unroll
         for (int i = 0; i < LA; ++i) {
             const int gmc = min(m0 + ldrow + i * RP, g.M - 1);
-            aoff[i] = ((unsigned)gmc * (unsigned)g.lda + (unsigned)(ldc4 * 4)) * 4u;
+            if (APRO == 3) {
+                const int hw = g.cv.Ho * g.cv.Wo;
+                const int bimg = gmc / hw, rem = gmc - bimg * hw;
+                const int yo = rem / g.cv.Wo, xo = rem - yo * g.cv.Wo;
+                cy[i] = yo * g.cv.stride;
+                cx[i] = xo * g.cv.stride;
+                aoff[i] = (unsigned)bimg * (unsigned)(g.cv.Hi * g.cv.Wi);  // position index of the image's (0, 0)
+            } else {
+                aoff[i] = ((unsigned)gmc * (unsigned)g.lda + (unsigned)(ldc4 * 4)) * 4u;
+            }
             if (APRO == 1) soff[i] = ((unsigned)(gmc / g.a_rows_per_sample) * (unsigned)g.K + (unsigned)(ldc4 * 4)) * 4u;
         }
 #pragma unroll
         for (int i = 0; i < LB; ++i) boff[i] = ((unsigned)min(n0 + ldrow + i * RP, g.N - 1) * (unsigned)g.ldw + (unsigned)(ldc4 * 4)) * 4u;
     };
     set_tile(ltile);
+    if (APRO == 3) {
+        ltap = (lkt * BK) / g.cv.C;
+        lc0 = lkt * BK - ltap * g.cv.C;
+    }
     if (APRO == 2) {
         // LayerNorm-on-load: combine the producer's per-16-column (sum, sumsq) partials of this thread's rows; the 8 lanes that
         // share a row (tid & 7) split the blocks and xor-reduce.  fp64 for the final E[x^2] - mean^2.  Computed ONCE: the host
@@ -164,9 +181,22 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 &
 
     auto load_unit = [&](Stage& r) __attribute__((always_inline)) {  // loads the unit under the load cursor
         const int kofs = lkt * (BK * 4);  // uniform byte offset of this K step -> the loads' SGPR offset
+        int oy = 0, ox = 0;
+        if (APRO == 3) {
+            const int o = g.cv.off[ltap];  // uniform: one scalar load from the kernel arguments
+            oy = o >> 16;
+            ox = (int)(short)(o & 0xffff);
+        }
 #pragma unroll
         for (int i = 0; i < LA; ++i) {
-            r.a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcA, aoff[i], kofs, 0));
+            if (APRO == 3) {
+                const int yy = cy[i] + oy, xx = cx[i] + ox;
+                r.ok[i] = (unsigned)yy < (unsigned)g.cv.Hi && (unsigned)xx < (unsigned)g.cv.Wi;
+                const unsigned pos = aoff[i] + (unsigned)(min(max(yy, 0), g.cv.Hi - 1) * g.cv.Wi + min(max(xx, 0), g.cv.Wi - 1));
+                r.a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcA, (pos * (unsigned)g.cv.C + (unsigned)(ldc4 * 4)) * 4u, lc0 * 4, 0));
+            } else {
+                r.a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcA, aoff[i], kofs, 0));
+            }
             if (APRO == 1) r.s[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcS, soff[i], kofs, 0));
         }
         if (APRO == 1) r.t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcT, (unsigned)(ldc4 * 16), kofs, 0));
@@ -183,7 +213,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 &
             f32x4 v = r.a[i];
             if (APRO == 1) v = v * r.s[i] + r.t;
             if (APRO == 2) v = (v - ln_mu[i]) * ln_rs[i];
-            if (!r.kok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (!r.kok || (APRO == 3 && !r.ok[i])) v = f32x4{0.f, 0.f, 0.f, 0.f};
             if (LA * RP == BM || row < BM) *reinterpret_cast<f32x4*>(As + row * BK + ((ldc4 ^ (row & (SL - 1))) << 2)) = v;
         }
 #pragma unroll
@@ -427,10 +457,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 &
     int loaded = 0;  // units fetched so far; the load cursor stops on the range's last unit (re-reading it hits L1/L2)
     auto fetch = [&](Stage& r) __attribute__((always_inline)) {
         load_unit(r);
-        if (++loaded < n && ++lkt == KT) {  // workgroup-uniform; never runs into the next workgroup's units
-            lkt = 0;
-            ++ltile;
-            set_tile(ltile);
+        if (++loaded < n) {  // workgroup-uniform; never runs into the next workgroup's units
+            if (APRO == 3 && (lc0 += BK) == g.cv.C) { lc0 = 0; ++ltap; }
+            if (++lkt == KT) {
+                lkt = 0;
+                ltap = 0;
+                lc0 = 0;
+                ++ltile;
+                set_tile(ltile);
+            }
         }
     };
 #pragma unroll
@@ -528,9 +563,22 @@ static const TileCfg kCfgs[] = {
 static const int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 int gemm_num_tile_configs() { return kNumCfgs; }
 
+// tile configs that carry the implicit-convolution variant (ids 2, 5, 9, 10, 14, 18)
+template <int WM, int WN, int TM, int TN, int PD, int BK>
+static constexpr bool conv_tile() {
+    return BK == 32 && ((WM == 2 && WN == 2 && TM == TN && (TM == 1 || TM == 2)) || (WM * WN == 8 && WM * TM == 8 && WN * TN == 8) || (WM == 4 && WN == 2 && TM == 2 && TN == 2));
+}
+static bool conv_cfg(int cfg) { return cfg == 2 || cfg == 5 || cfg == 9 || cfg == 10 || cfg == 14 || cfg == 18 || cfg == 19; }
+
 template <int WM, int WN, int TM, int TN, int PD, int BK>
 static void launch_one(const GemmArgs& g, const SkPlan& p, unsigned G, float* slabs, unsigned* tickets, unsigned slab_bytes, hipStream_t st) {
     constexpr int NT = 64 * WM * WN;
+    if constexpr (conv_tile<WM, WN, TM, TN, PD, BK>()) {
+        if (g.cv.enabled) {
+            hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, PD, 3, false, BK>), dim3(G), dim3(NT), 0, st, g, p, slabs, tickets, slab_bytes);
+            return;
+        }
+    }
     if (g.a_scale)
         hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, PD, 1, false, BK>), dim3(G), dim3(NT), 0, st, g, p, slabs, tickets, slab_bytes);
     else if (g.ln_stats)
@@ -673,15 +721,24 @@ static int launch_gemm_cfg_impl(const GemmArgs& g, int cfg, int splitk, void* ws
         const int rc = launch_gemm_bf16(g, -1, 1, ws, ws_bytes, st);
         if (rc != PAELLA_ERR_STATE) return rc;
     }
+    if (g.cv.enabled) {
+        if (g.a_scale || g.ln_stats || g.cv.ntaps < 1 || g.cv.ntaps > 16 || (g.cv.C & 31) || g.K != g.cv.ntaps * g.cv.C || g.cv.Ho < 1 || g.cv.Wo < 1 ||
+            g.M % (g.cv.Ho * g.cv.Wo) || (size_t)(g.M / (g.cv.Ho * g.cv.Wo)) * g.cv.Hi * g.cv.Wi * g.cv.C * sizeof(float) > 0xffffffffull) {
+            paella_set_error("gemm: bad implicit-convolution descriptor (C=%d must be a multiple of 32, K=%d == ntaps*C, M=%d a multiple of Ho*Wo)", g.cv.C, g.K, g.M);
+            return PAELLA_ERR_ARG;
+        }
+    }
     const bool have_ws = ws && ws_bytes > kGemmTicketBytes;
     const size_t slab_cap = have_ws ? ws_bytes - kGemmTicketBytes : 0;
     unsigned G = 0;
     if (cfg < 0) {
         choose_config(g.M, g.N, g.K, g.a_scale ? 1 : (g.ln_stats ? 2 : 0), slab_cap, &cfg, &G);
+        if (g.cv.enabled && !conv_cfg(cfg)) { paella_set_error("internal: heuristic picked tile %d without a convolution variant", cfg); return PAELLA_ERR_STATE; }
     } else {
         if (cfg >= kNumCfgs) { paella_set_error("gemm: bad tile config %d", cfg); return PAELLA_ERR_ARG; }
         const long T = tiles_of_cfg(cfg, g.M, g.N);
         G = splitk < 0 ? (unsigned)(-splitk) : (unsigned)(T * (splitk < 1 ? 1 : splitk));
+        if (g.cv.enabled && !conv_cfg(cfg)) { paella_set_error("gemm: tile config %d has no implicit-convolution variant", cfg); return PAELLA_ERR_ARG; }
     }
     const TileCfg& tc = kCfgs[cfg];
     const int BM = tc.wm * tc.tm * 16, BN = tc.wn * tc.tn * 16;

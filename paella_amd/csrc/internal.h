@@ -51,5 +51,6 @@ static inline GemmArgs gemm_args(const float* A, int lda, const float* Wt, int l
     g.ep = make_epilogue();
     g.ft.temperature = 1.f; g.ft.mode = 0; g.ft.seed = 0; g.ft.seed_ptr = nullptr; g.ft.offset = 0; g.ft.row_offset = 0;
     g.ft.part_score = nullptr; g.ft.part_idx = nullptr;
+    g.cv.enabled = 0;
     return g;
 }

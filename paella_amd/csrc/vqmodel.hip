@@ -285,8 +285,20 @@ static int vq_run_decoder(paella_vqgan* v, VqBuffers& f, int B, int h, int w, fl
             case VQ_CONVT4: {  // 4 output phases, each a gather + GEMM with a strided (depth-to-space) store into f.t
                 for (int ph = 0; ph < 4; ++ph) {
                     const int py = ph >> 1, px = ph & 1;
-                    RET_IF(launch_convT4_gather(f.x, f.a, B, ch, cw, b.c_in, py, px, st));
-                    GemmArgs g = gemm_args(f.a, 4 * b.c_in, b.phase_w[ph].p, 4 * b.c_in, f.t, b.c_out, (int)rows, b.c_out, 4 * b.c_in);
+                    // implicit GEMM: the 2x2 taps of this phase are gathered in the GEMM's operand load (no [rows, 4*c_in] buffer);
+                    // channel counts that are not a multiple of the K step (tiny test models) take the materialised operand
+                    const bool implicit = (b.c_in & 31) == 0;
+                    if (!implicit) RET_IF(launch_convT4_gather(f.x, f.a, B, ch, cw, b.c_in, py, px, st));
+                    GemmArgs g = gemm_args(implicit ? f.x : f.a, 4 * b.c_in, b.phase_w[ph].p, 4 * b.c_in, f.t, b.c_out, (int)rows, b.c_out, 4 * b.c_in);
+                    if (implicit) {
+                        g.cv.enabled = 1; g.cv.Hi = ch; g.cv.Wi = cw; g.cv.C = b.c_in; g.cv.Ho = ch; g.cv.Wo = cw; g.cv.stride = 1; g.cv.ntaps = 4;
+                        for (int t = 0; t < 4; ++t) {  // tap (ty, tx) -> input offset, as src/vqgan.py:83-85 unrolled per output phase
+                            const int ty = t >> 1, tx = t & 1;
+                            const int oy = py == 0 ? (ty == 0 ? 0 : -1) : (ty == 0 ? 1 : 0);
+                            const int ox = px == 0 ? (tx == 0 ? 0 : -1) : (tx == 0 ? 1 : 0);
+                            g.cv.off[t] = (int)(((unsigned)oy << 16) | ((unsigned)ox & 0xffffu));
+                        }
+                    }
                     g.ep.bias = VT(v, b.prefix + ".bias");
                     g.ep.store_mode = STORE_D2S; g.ep.sH = ch; g.ep.sW = cw; g.ep.sC = b.c_out; g.ep.n_seg_x = 1; g.ep.py = py; g.ep.px = px;
                     RET_IF(launch_gemm(g, f.splitk, kSplitKBudget, st));
@@ -377,9 +389,14 @@ extern "C" int paella_vqgan_encode(paella_vqgan* v, const float* img, int B, int
             }
             case VQ_RES: RET_IF(vq_resblock(v, b, f, B, ch, cw, st)); break;
             case VQ_CONV4S2: {
-                RET_IF(launch_conv4s2_im2col(f.x, f.a, B, ch, cw, b.c_in, st));
+                const bool implicit = (b.c_in & 31) == 0;  // implicit GEMM (no im2col buffer) whenever the K step divides the channel count
+                if (!implicit) RET_IF(launch_conv4s2_im2col(f.x, f.a, B, ch, cw, b.c_in, st));
+                GemmArgs g = gemm_args(implicit ? f.x : f.a, 16 * b.c_in, VT(v, b.prefix + ".weight"), 16 * b.c_in, f.t, b.c_out, (int)(rows / 4), b.c_out, 16 * b.c_in);
+                if (implicit) {
+                    g.cv.enabled = 1; g.cv.Hi = ch; g.cv.Wi = cw; g.cv.C = b.c_in; g.cv.Ho = ch / 2; g.cv.Wo = cw / 2; g.cv.stride = 2; g.cv.ntaps = 16;
+                    for (int t = 0; t < 16; ++t) g.cv.off[t] = (int)(((unsigned)((t >> 2) - 1) << 16) | ((unsigned)((t & 3) - 1) & 0xffffu));  // Conv2d(k4, s2, p1): src/vqgan.py:61
+                }
                 ch >>= 1; cw >>= 1;
-                GemmArgs g = gemm_args(f.a, 16 * b.c_in, VT(v, b.prefix + ".weight"), 16 * b.c_in, f.t, b.c_out, (int)(rows / 4), b.c_out, 16 * b.c_in);
                 g.ep.bias = VT(v, b.prefix + ".bias");
                 RET_IF(launch_gemm(g, f.splitk, kSplitKBudget, st));
                 float* tmp = f.x; f.x = f.t; f.t = tmp;
