@@ -85,12 +85,12 @@ struct FusedTail {
 
 // Implicit-GEMM convolution (VQGAN k4 s2 p1 Conv2d / the 4 output phases of the k4 s2 p1 ConvTranspose2d, reference src/vqgan.py:59-61,
 // 81-85): the A operand is never materialised.  Row m = output position (b, yo, xo) on a [Ho, Wo] grid, K index = tap * C + c,
-// A[m][tap*C + c] = x[b][yo*stride + oy[tap]][xo*stride + ox[tap]][c] (0 outside the [Hi, Wi] input grid), x = GemmArgs::A in NHWC.
+// A[m][tap*C + c] = x[b][yo*stride + oy(tap)][xo*stride + ox(tap)][c] (0 outside the [Hi, Wi] input grid), x = GemmArgs::A in NHWC.
 // The gather happens in the GEMM's operand load (per-row offsets + a per-K-step tap offset); needs C % (K step) == 0.
 struct ConvGather {
     int enabled;
     int Hi, Wi, C, Ho, Wo, stride, ntaps;
-    int off[16];  // per tap: (oy << 16) | (ox & 0xffff)
+    int tw_log2, oy0, ox0, tsign;  // tap t = (ty, tx) = (t >> tw_log2, t & (2^tw_log2 - 1)); offset (oy, ox) = (oy0 + tsign*ty, ox0 + tsign*tx)
 };
 
 struct GemmArgs {

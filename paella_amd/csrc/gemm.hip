@@ -122,11 +122,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 &
     auto rsrc_of = [](const float* ptr, size_t bytes) {
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ptr), 0, (int)(bytes > 0xffffffffull ? 0xffffffffull : bytes), 0x00020000);
     };
-    const __amdgpu_buffer_rsrc_t rsrcA = rsrc_of(g.A, APRO == 3 ? (size_t)(g.M / (g.cv.Ho * g.cv.Wo)) * g.cv.Hi * g.cv.Wi * g.cv.C * sizeof(float)
-                                                             : ((size_t)(g.M - 1) * g.lda + g.K) * sizeof(float));
-    const __amdgpu_buffer_rsrc_t rsrcW = rsrc_of(g.W, ((size_t)(g.N - 1) * g.ldw + g.K) * sizeof(float));
-    const __amdgpu_buffer_rsrc_t rsrcS = rsrc_of(APRO == 1 ? g.a_scale : g.A,
-                                                 APRO == 1 ? (size_t)((g.M - 1) / g.a_rows_per_sample + 1) * g.K * sizeof(float) : 16);
+    // descriptors are re-based on every tile (first row of the tile / first image of the tile): per-thread offsets stay far below
+    // 4 GiB whatever the operand size, and the range check still ends at the true end of each operand
+    const size_t a_bytes = APRO == 3 ? (size_t)(g.M / (g.cv.Ho * g.cv.Wo)) * g.cv.Hi * g.cv.Wi * g.cv.C * sizeof(float)
+                                     : ((size_t)(g.M - 1) * g.lda + g.K) * sizeof(float);
+    const size_t w_bytes = ((size_t)(g.N - 1) * g.ldw + g.K) * sizeof(float);
+    __amdgpu_buffer_rsrc_t rsrcA = rsrc_of(g.A, a_bytes), rsrcW = rsrc_of(g.W, w_bytes);
+    __amdgpu_buffer_rsrc_t rsrcS = rsrc_of(g.A, 16);
     const __amdgpu_buffer_rsrc_t rsrcT = rsrc_of(APRO == 1 ? g.a_shift : g.A, APRO == 1 ? (size_t)g.K * sizeof(float) : 16);
     unsigned aoff[LA], soff[APRO == 1 ? LA : 1], boff[LB];
     int cy[APRO == 3 ? LA : 1], cx[APRO == 3 ? LA : 1];  // implicit conv: top-left input coordinate of row i (aoff[i] = image base position)
@@ -136,6 +138,22 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 &
         const int tile_m = tile % p.tiles_m;  // m fastest: consecutive tiles share the weight panel
         const int tile_n = tile / p.tiles_m;
         const int m0 = tile_m * BM, n0 = tile_n * BN;
+        size_t a_base;  // bytes from g.A to this tile's descriptor base
+        int img0 = 0, smp0 = 0;
+        if (APRO == 3) {
+            img0 = m0 / (g.cv.Ho * g.cv.Wo);
+            a_base = (size_t)img0 * g.cv.Hi * g.cv.Wi * g.cv.C * sizeof(float);
+        } else {
+            a_base = (size_t)m0 * g.lda * sizeof(float);
+        }
+        rsrcA = rsrc_of(reinterpret_cast<const float*>(reinterpret_cast<const char*>(g.A) + a_base), a_bytes - a_base);
+        const size_t w_base = (size_t)n0 * g.ldw * sizeof(float);
+        rsrcW = rsrc_of(reinterpret_cast<const float*>(reinterpret_cast<const char*>(g.W) + w_base), w_bytes - w_base);
+        if (APRO == 1) {
+            smp0 = m0 / g.a_rows_per_sample;
+            const size_t s_bytes = (size_t)((g.M - 1) / g.a_rows_per_sample + 1) * g.K * sizeof(float), s_base = (size_t)smp0 * g.K * sizeof(float);
+            rsrcS = rsrc_of(g.a_scale + (size_t)smp0 * g.K, s_bytes - s_base);
+        }
 #pragma unroll
         for (int i = 0; i < LA; ++i) {
             const int gmc = min(m0 + ldrow + i * RP, g.M - 1);
@@ -145,14 +163,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 &
                 const int yo = rem / g.cv.Wo, xo = rem - yo * g.cv.Wo;
                 cy[i] = yo * g.cv.stride;
                 cx[i] = xo * g.cv.stride;
-                aoff[i] = (unsigned)bimg * (unsigned)(g.cv.Hi * g.cv.Wi);  // position index of the image's (0, 0)
+                aoff[i] = (unsigned)(bimg - img0) * (unsigned)(g.cv.Hi * g.cv.Wi);  // position index of the image's (0, 0), relative to the tile's first image
             } else {
-                aoff[i] = ((unsigned)gmc * (unsigned)g.lda + (unsigned)(ldc4 * 4)) * 4u;
+                aoff[i] = ((unsigned)(gmc - m0) * (unsigned)g.lda + (unsigned)(ldc4 * 4)) * 4u;
             }
-            if (APRO == 1) soff[i] = ((unsigned)(gmc / g.a_rows_per_sample) * (unsigned)g.K + (unsigned)(ldc4 * 4)) * 4u;
+            if (APRO == 1) soff[i] = ((unsigned)(gmc / g.a_rows_per_sample - smp0) * (unsigned)g.K + (unsigned)(ldc4 * 4)) * 4u;
         }
 #pragma unroll
-        for (int i = 0; i < LB; ++i) boff[i] = ((unsigned)min(n0 + ldrow + i * RP, g.N - 1) * (unsigned)g.ldw + (unsigned)(ldc4 * 4)) * 4u;
+        for (int i = 0; i < LB; ++i) boff[i] = ((unsigned)(min(n0 + ldrow + i * RP, g.N - 1) - n0) * (unsigned)g.ldw + (unsigned)(ldc4 * 4)) * 4u;
     };
     set_tile(ltile);
     if (APRO == 3) {
@@ -183,9 +201,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 &
         const int kofs = lkt * (BK * 4);  // uniform byte offset of this K step -> the loads' SGPR offset
         int oy = 0, ox = 0;
         if (APRO == 3) {
-            const int o = g.cv.off[ltap];  // uniform: one scalar load from the kernel arguments
-            oy = o >> 16;
-            ox = (int)(short)(o & 0xffff);
+            oy = g.cv.oy0 + g.cv.tsign * (ltap >> g.cv.tw_log2);  // uniform scalar arithmetic
+            ox = g.cv.ox0 + g.cv.tsign * (ltap & ((1 << g.cv.tw_log2) - 1));
         }
 #pragma unroll
         for (int i = 0; i < LA; ++i) {
@@ -712,10 +729,6 @@ static int launch_gemm_cfg_impl(const GemmArgs& g, int cfg, int splitk, void* ws
         paella_set_error("gemm: depth-to-space store needs channels %% 4 == 0");
         return PAELLA_ERR_ARG;
     }
-    if (((size_t)(g.M - 1) * g.lda + g.K) * sizeof(float) > 0xffffffffull || ((size_t)(g.N - 1) * g.ldw + g.K) * sizeof(float) > 0xffffffffull) {
-        paella_set_error("gemm: an operand of 4 GiB or more (M=%d lda=%d N=%d ldw=%d): split the rows -- operands are read through 32-bit buffer offsets", g.M, g.lda, g.N, g.ldw);
-        return PAELLA_ERR_ARG;
-    }
     if (cfg >= 96 && cfg < 99) return launch_gemm_bf16(g, cfg - 96, splitk, ws, ws_bytes, st);  // explicit bf16 tile (tests / tools)
     if (cfg < 0 && gemm_precision() == 1) {  // opt-in fast mode: bf16 operands where a shadow weight exists
         const int rc = launch_gemm_bf16(g, -1, 1, ws, ws_bytes, st);
@@ -723,7 +736,8 @@ static int launch_gemm_cfg_impl(const GemmArgs& g, int cfg, int splitk, void* ws
     }
     if (g.cv.enabled) {
         if (g.a_scale || g.ln_stats || g.cv.ntaps < 1 || g.cv.ntaps > 16 || (g.cv.C & 31) || g.K != g.cv.ntaps * g.cv.C || g.cv.Ho < 1 || g.cv.Wo < 1 ||
-            g.M % (g.cv.Ho * g.cv.Wo) || (size_t)(g.M / (g.cv.Ho * g.cv.Wo)) * g.cv.Hi * g.cv.Wi * g.cv.C * sizeof(float) > 0xffffffffull) {
+            g.M % (g.cv.Ho * g.cv.Wo)
+            || (size_t)2 * g.cv.Hi * g.cv.Wi * g.cv.C * sizeof(float) > 0xffffffffull) {
             paella_set_error("gemm: bad implicit-convolution descriptor (C=%d must be a multiple of 32, K=%d == ntaps*C, M=%d a multiple of Ho*Wo)", g.cv.C, g.K, g.M);
             return PAELLA_ERR_ARG;
         }

@@ -292,12 +292,8 @@ static int vq_run_decoder(paella_vqgan* v, VqBuffers& f, int B, int h, int w, fl
                     GemmArgs g = gemm_args(implicit ? f.x : f.a, 4 * b.c_in, b.phase_w[ph].p, 4 * b.c_in, f.t, b.c_out, (int)rows, b.c_out, 4 * b.c_in);
                     if (implicit) {
                         g.cv.enabled = 1; g.cv.Hi = ch; g.cv.Wi = cw; g.cv.C = b.c_in; g.cv.Ho = ch; g.cv.Wo = cw; g.cv.stride = 1; g.cv.ntaps = 4;
-                        for (int t = 0; t < 4; ++t) {  // tap (ty, tx) -> input offset, as src/vqgan.py:83-85 unrolled per output phase
-                            const int ty = t >> 1, tx = t & 1;
-                            const int oy = py == 0 ? (ty == 0 ? 0 : -1) : (ty == 0 ? 1 : 0);
-                            const int ox = px == 0 ? (tx == 0 ? 0 : -1) : (tx == 0 ? 1 : 0);
-                            g.cv.off[t] = (int)(((unsigned)oy << 16) | ((unsigned)ox & 0xffffu));
-                        }
+                        // tap (ty, tx) of output phase (py, px) reads input (y + py - ty, x + px - tx): src/vqgan.py:83-85 unrolled per phase
+                        g.cv.tw_log2 = 1; g.cv.oy0 = py; g.cv.ox0 = px; g.cv.tsign = -1;
                     }
                     g.ep.bias = VT(v, b.prefix + ".bias");
                     g.ep.store_mode = STORE_D2S; g.ep.sH = ch; g.ep.sW = cw; g.ep.sC = b.c_out; g.ep.n_seg_x = 1; g.ep.py = py; g.ep.px = px;
@@ -394,7 +390,7 @@ extern "C" int paella_vqgan_encode(paella_vqgan* v, const float* img, int B, int
                 GemmArgs g = gemm_args(implicit ? f.x : f.a, 16 * b.c_in, VT(v, b.prefix + ".weight"), 16 * b.c_in, f.t, b.c_out, (int)(rows / 4), b.c_out, 16 * b.c_in);
                 if (implicit) {
                     g.cv.enabled = 1; g.cv.Hi = ch; g.cv.Wi = cw; g.cv.C = b.c_in; g.cv.Ho = ch / 2; g.cv.Wo = cw / 2; g.cv.stride = 2; g.cv.ntaps = 16;
-                    for (int t = 0; t < 16; ++t) g.cv.off[t] = (int)(((unsigned)((t >> 2) - 1) << 16) | ((unsigned)((t & 3) - 1) & 0xffffu));  // Conv2d(k4, s2, p1): src/vqgan.py:61
+                    g.cv.tw_log2 = 2; g.cv.oy0 = -1; g.cv.ox0 = -1; g.cv.tsign = 1;  // Conv2d(k4, s2, p1): tap (ky, kx) reads (2*yo - 1 + ky, 2*xo - 1 + kx), src/vqgan.py:61
                 }
                 ch >>= 1; cw >>= 1;
                 g.ep.bias = VT(v, b.prefix + ".bias");
