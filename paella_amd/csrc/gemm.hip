@@ -54,7 +54,9 @@ template <int WM, int WN, int TM, int TN, int PD, int APRO, bool TAIL = false, i
 // The 32x32 tile is the batch-1 workhorse and wants 5 workgroups per CU (1280 resident): ask for <= 96 VGPRs there.  Not for the
 // GRN-prologue variant (two more staged operands per unit): forced under 96 registers it spills inside the unit loop (measured
 // 33 us instead of 25 for 128x1280x5120), so it runs 4 workgroups per CU and the heuristic gives it at most 1024 workgroups.
-__global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 && PD == 2 && BK == 32 && APRO != 1) ? 5 : 1) void gemm_nt_kernel(GemmArgs g, SkPlan p, float* __restrict__ slabs,
+// The 8-wave 128x64 tiles fit 128 VGPRs without spilling when asked to (126 / 128): two workgroups per CU instead of one.
+__global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 && PD == 2 && BK == 32 && APRO != 1) ? 5
+                                           : ((WM * WN == 8 && WM * TM == 8 && WN * TN == 4 && PD == 2 && BK == 32 && APRO == 0 && !TAIL) ? 4 : 1)) void gemm_nt_kernel(GemmArgs g, SkPlan p, float* __restrict__ slabs,
                                                                unsigned* __restrict__ tickets, unsigned slab_bytes) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
     constexpr int SL = BK / 4;     // 16-byte slots per LDS row; slot s of row r lives at s ^ (r & (SL - 1)): conflict-free ds_write_b128 / ds_read_b128
@@ -609,13 +611,14 @@ static inline long tiles_of_cfg(int c, int M, int N) {
     return (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
 }
 
-// Tile / workgroup-count choice, fitted to tools/gemm_tune.py sweeps on MI355X (profiles/r02_gemm_tile_sweep.txt).
+// Tile / workgroup-count choice, fitted to tools/gemm_tune.py sweeps on MI355X (profiles/r02_gemm_tile_sweep*.txt).
 // Returns the tile config and G (number of workgroups = number of contiguous unit ranges).  What the sweeps show:
-//  * >= 1024 tiles of 128x128: one tile per workgroup, 8 waves (cfg 10): 127-133 TFLOP/s at any K;
-//  * fewer tiles but >= 5 GFLOP: the same tile with G = 512 balanced ranges (2 workgroups per CU; every CU busy whatever the tile
-//    count: 1024x1280x5120 runs 125 us where one-tile-per-workgroup 64x64 tiles took 150);
-//  * 2.4-5 GFLOP: 128x64 tiles, 8 waves, one workgroup per CU (G = 256);
-//  * many small tiles with a short K (VQGAN full-resolution levels): 64x64 tiles, one each;
+//  * >= 1024 tiles of 128x128: one tile per workgroup, 8 waves (cfg 10): 124-133 TFLOP/s at any K;
+//  * fewer 128-tiles but >= 2.4 GFLOP (the batched mid-size shapes, e.g. 4096x1280x1280, 1024x1280x5120, 4096x640x2560): 64x64
+//    tiles with a 1-deep ring (cfg 18: 4 workgroups per CU resident, 3 with the LayerNorm prologue) -- one tile per workgroup when
+//    there are >= 2048 of them, else every resident slot gets one balanced range of (tile, K-step) units.  Within 5 % of the best
+//    variant on every shape swept and 10-15 % ahead of 128x128 tiles in 512 ranges (which run as two rounds: that tile holds one
+//    workgroup per CU);
 //  * skinny batch-1 shapes: 32x32 tiles, ~10 K-steps per workgroup, at most 1280 workgroups = 5 per CU, all resident at once
 //    (__launch_bounds__(256, 5) on that instantiation guarantees the registers for it) -- every larger
 //    tile lands within 5 % of it (24-27 us for 128x5120x1280): these launches are bound by ramp + combine, not by the tile.
@@ -626,10 +629,11 @@ static void choose_config(int M, int N, int K, int apro, size_t slab_cap_bytes, 
     int cfg;
     long G;
     if (T128 >= 1024) { cfg = 10; G = T128; }
-    else if (macs >= 2.5e9) { cfg = 10; G = T128 * ktiles >= 512 * 3 ? 512 : T128; }
-    else if (macs >= 1.2e9) { cfg = 14; G = 256; }
-    else if (T64 >= 1024) { cfg = 18; G = T64; }
-    else {
+    else if (macs >= 1.2e9 || T64 >= 1024) {
+        cfg = 18;
+        const long resident = apro == 2 ? 768 : 1024;
+        G = (T64 >= 2048 || ktiles < 16) ? T64 : resident;  // short K: ranges would be mostly partial tiles
+    } else {
         cfg = 5;
         const long U = T32 * ktiles;
         G = U / 10;

@@ -871,6 +871,16 @@ extern "C" int paella_op_gemm(const float* A, const float* W, const float* bias,
     g.ep.bias = bias; g.ep.act = act; g.ep.residual = residual; g.ep.ldr = N;
     return launch_gemm_cfg(g, tile_cfg, splitk, ws, ws_bytes, (hipStream_t)stream);
 }
+// test hook (test_hooks.h): the A-operand prologue variants of the GEMM with an explicit tile config / workgroup count
+extern "C" int paella_test_gemm_prologue(const float* A, const float* W, float* C, int M, int N, int K, int mode, const float* scale,
+                                         const float* shift, int rows_per_sample, const float* ln_stats, int tile_cfg, int splitk, void* ws,
+                                         size_t ws_bytes, void* stream) {
+    GemmArgs g = gemm_args(A, K, W, K, C, N, M, N, K);
+    if (mode == 1) { g.a_scale = scale; g.a_shift = shift; g.a_rows_per_sample = rows_per_sample; }
+    else if (mode == 2) { g.ln_stats = ln_stats; g.ln_nblk = K / 16; g.ln_eps = 1e-6f; }
+    else if (mode != 0) { paella_set_error("prologue mode must be 0, 1 (scale / shift per sample) or 2 (LayerNorm from row statistics)"); return PAELLA_ERR_ARG; }
+    return launch_gemm_cfg(g, tile_cfg, splitk, ws, ws_bytes, (hipStream_t)stream);
+}
 extern "C" int paella_test_register_weight(const float* w, size_t numel, int on) {
     if (on) return gemm_register_weight(w, numel, 0);
     gemm_unregister_weight(w);

@@ -12,6 +12,11 @@ int paella_test_register_weight(const float* w, size_t numel, int on);
 int paella_test_launch_chain(float* buf, int n_elems, int blocks, int n_launches, void* stream);
 /* 1 = run large-query-count attention on the register-fed kernel instead of the LDS-staged one (A/B probe, tools/attn_probe.py) */
 int paella_test_attention_variant(int v);
+/* C = prologue(A) . W^T with an explicit tile config / workgroup count (as paella_op_gemm): mode 1: a' = a * scale[row / rows_per_sample][k] +
+ * shift[k] (the GRN apply of the MLP's second GEMM); mode 2: a' = (a - mean) * rstd from ln_stats [M, K/16, 2] = per 16-column block (sum, sum of
+ * squares) (LayerNorm folded into the consumer) */
+int paella_test_gemm_prologue(const float* A, const float* W, float* C, int M, int N, int K, int mode, const float* scale, const float* shift,
+                              int rows_per_sample, const float* ln_stats, int tile_cfg, int splitk, void* ws, size_t ws_bytes, void* stream);
 #ifdef __cplusplus
 }
 #endif

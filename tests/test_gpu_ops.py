@@ -71,6 +71,35 @@ def test_gemm_every_tile_config(lib, cfg, splitk):
     np.testing.assert_allclose(C.cpu().numpy(), ref.numpy(), atol=1e-3, rtol=2e-5)
 
 
+@pytest.mark.parametrize("cfg", range(N_TILE_CONFIGS))
+@pytest.mark.parametrize("mode,splitk", [(1, 1), (1, -37), (2, 1), (2, 3), (2, -37)])
+def test_gemm_operand_prologues_every_tile_config(lib, cfg, mode, splitk):
+    """The A-operand prologues the model fuses into its GEMMs (test hook): mode 1 = GRN apply a * scale[sample][k] + shift[k]
+    (src/modules.py:36-40 folded into channelwise.4), mode 2 = LayerNorm (no affine, eps 1e-6) from the producer's per-16-column
+    (sum, sum of squares) -- on every tile config, one tile per workgroup / split-K / balanced unit ranges, ragged M and N, samples
+    that straddle tile boundaries."""
+    rps, B, N, K = 24, 9, 168, 416
+    M = rps * B  # 216 rows: not a multiple of any tile height
+    g = torch.Generator().manual_seed(cfg * 100 + mode * 10 + abs(splitk))
+    A = torch.randn(M, K, generator=g) * 1.5 + 0.3 + torch.arange(K)[None, :] * 0.004
+    W = torch.randn(N, K, generator=g) / K ** 0.5 + torch.arange(N)[:, None] * 0.001
+    scale = 1.0 + 0.3 * torch.randn(B, K, generator=g)
+    shift = 0.2 * torch.randn(K, generator=g)
+    blk = A.view(M, K // 16, 16)
+    stats = torch.stack([blk.sum(-1), (blk * blk).sum(-1)], dim=-1).contiguous()
+    if mode == 1:
+        a2 = A.double() * scale.double().repeat_interleave(rps, dim=0) + shift.double()
+    else:
+        a2 = F.layer_norm(A.double(), (K,), None, None, 1e-6)
+    ref = (a2 @ W.double().t()).float()
+    C = torch.full((M, N), float("nan"), device="cuda")
+    ws = _lib.new_workspace(64 << 20, "cuda")
+    Ad, Wd, sc, sh, sd = A.cuda(), W.cuda(), scale.cuda(), shift.cuda(), stats.cuda()
+    _check(lib, lib.paella_test_gemm_prologue(_p(Ad), _p(Wd), _p(C), M, N, K, mode, _p(sc), _p(sh), rps, _p(sd), cfg, splitk, _p(ws), ws.numel(), _st()))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(C.cpu().numpy(), ref.numpy(), atol=2e-4, rtol=2e-5)
+
+
 @pytest.mark.parametrize("cfg,G", [(5, 512), (11, 512), (12, 256), (12, 509), (13, 768), (14, 256), (16, 256), (22, 640), (9, 300), (2, 1000), (24, 512), (25, 777), (26, 100), (29, 64)])
 def test_gemm_stream_k_is_repeatable(lib, cfg, G):
     """Balanced unit ranges (partial tiles combined by the last arriver in fixed part order): many back-to-back launches on

@@ -34,6 +34,9 @@ SHAPES = {
     "b32 L1 mlp1 4096x5120x1280": (4096, 5120, 1280), "b32 L1 mlp2 4096x1280x5120": (4096, 1280, 5120), "b32 L1 qkv 4096x3840x1280": (4096, 3840, 1280),
     "b32 L1 out 4096x1280x1280": (4096, 1280, 1280), "b32 L0 mlp1 16384x2560x640": (16384, 2560, 640), "b32 L2 mlp1 1024x5120x1280": (1024, 5120, 1280),
     "b32 L2 mlp2 1024x1280x5120": (1024, 1280, 5120),
+    "b32 L0 mlp2 16384x640x2560": (16384, 640, 2560), "b32 L2 qkv 1024x3840x1280": (1024, 3840, 1280), "b32 L2 out 1024x1280x1280": (1024, 1280, 1280),
+    "c3 L2 mlp2 8192x1280x5120": (8192, 1280, 5120), "c3 L2 out 8192x1280x1280": (8192, 1280, 1280), "c3 L2 qkv 8192x3840x1280": (8192, 3840, 1280),
+    "b32 pfx L0 mlp1 8192x2560x640": (8192, 2560, 640), "b32 pfx L0 mlp2 8192x640x2560": (8192, 640, 2560), "b32 clf 16384x1024x640": (16384, 1024, 640),
     "b8 L0 mlp1 4096x2560x640": (4096, 2560, 640), "b8 L0 mlp2 4096x640x2560": (4096, 640, 2560),
     "b8 L1 mlp1 1024x5120x1280": (1024, 5120, 1280), "b8 L1 mlp2 1024x1280x5120": (1024, 1280, 5120),
     "b8 L2 mlp1 256x5120x1280": (256, 5120, 1280), "b8 L2 mlp2 256x1280x5120": (256, 1280, 5120),
@@ -48,6 +51,7 @@ def main():
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--big-only", action="store_true", help="only the large-tile candidates without split-K")
     ap.add_argument("--only", default=None, help="substring filter on the shape name (comma-separated alternatives)")
+    ap.add_argument("--apro", type=int, default=0, choices=[0, 1, 2], help="A-operand prologue: 0 none, 1 GRN scale/shift (rows per sample = 64), 2 LayerNorm from row statistics")
     ap.add_argument("--cfgs", default=None, help="comma-separated tile configs to sweep (default: all that fit)")
     a = ap.parse_args()
     lib = _lib.load()
@@ -64,6 +68,10 @@ def main():
         A = torch.randn(M, K, device="cuda")
         Ws = [torch.randn(N, K, device="cuda") for _ in range(ncopy)]
         C = torch.empty(M, N, device="cuda")
+        rps = 64 if M % 64 == 0 else 16
+        scale = torch.ones(M // rps, K, device="cuda")
+        shift = torch.zeros(K, device="cuda")
+        stats = torch.stack([torch.zeros(M, K // 16, device="cuda"), torch.full((M, K // 16), 16.0, device="cuda")], dim=-1).contiguous()
         row = {}
         # (tile config, splitk): splitk > 0 = tiles * splitk workgroups (classic split-K), splitk < 0 = exactly -splitk
         # workgroups walking balanced contiguous (tile, K-step) ranges
@@ -81,7 +89,8 @@ def main():
         if a.big_only:
             variants = [(-1, 1)] + [(c, 1) for c in (0, 1, 2, 9, 10, 12, 14, 16, 18)]
         if M >= 4096:  # MFMA-bound: no split-K, few candidates, few iterations
-            variants = [(-1, 1)] + [(c, 1) for c in (0, 1, 2, 9, 10, 12, 14, 16, 18)]
+            variants = [(-1, 1)] + [(c, 1) for c in (0, 1, 2, 9, 10, 12, 14, 16, 18)] + \
+                       [(c, -G) for c in (2, 10, 14, 18) for G in (256, 512, 768, 1024)]
         for cfg, sk in variants:
             if sk > 1 and K // sk < 96:
                 continue
@@ -89,9 +98,12 @@ def main():
                 bm, bn = tile_of[cfg]
                 T = -(-M // bm) * -(-N // bn)
                 U = T * -(-K // bk_of[cfg])
-                if -sk > U or U / -sk < 2.5 or -sk < T // 2:   # too few units per workgroup / more than 2 tiles per workgroup
+                if -sk > U or U / -sk < 2.5 or -sk < T // 4:   # too few units per workgroup / more than 4 tiles per workgroup
                     continue
             def run(W):
+                if a.apro:
+                    return lib.paella_test_gemm_prologue(A.data_ptr(), W.data_ptr(), C.data_ptr(), M, N, K, a.apro, scale.data_ptr(), shift.data_ptr(), rps,
+                                                         stats.data_ptr(), cfg, sk, ws.data_ptr(), ws.numel(), st())
                 return lib.paella_op_gemm(A.data_ptr(), W.data_ptr(), None, None, C.data_ptr(), M, N, K, 0, cfg, sk, ws.data_ptr(), ws.numel(), st())
             if run(Ws[0]) != 0:
                 continue
