@@ -310,13 +310,14 @@ def main():
                 ce, ue = mk_cond(eb, 2), mk_cond(eb, 3)
                 sfn, efn = make_runner(eb, eg, es, 50000 * eb)
                 dte = timed(lambda: sfn(ce, ue), k, w, False, device)
-                r = gemm_roofline(lib, lambda: efn(ce, ue), device, a.model, eb, eg, es, a.gemm, False)
+                r = gemm_roofline(lib, lambda: efn(ce, ue), device, a.model, eb, eg, es, a.gemm, True)
                 throughput.append({"workload": "%s: batch %d per GPU, %dx%d tokens, %d steps, CFG 8.0, + VQGAN f8 decode"
                                                % (WORKLOAD_TAG.get((a.model, eb, eg, es), "configs[1] model at a throughput batch"), eb, eg, eg, es),
                                    "batch": eb, "grid": eg, "sample_steps": es, "steps": k, "warmup": w,
                                    "images_per_sec": round(eb * k / dte, 3), "ms_per_image": round(dte / (eb * k) * 1e3, 3),
                                    "roofline": {kk: r[kk] for kk in ("bound", "achieved", "peak", "unit", "frac", "executed_tflops", "executed_frac",
-                                                                      "launches_per_step", "avg_launch_us", "gemm_ms_per_step")}})
+                                                                      "launches_per_step", "avg_launch_us", "gemm_ms_per_step", "traffic", "traffic_source",
+                                                                      "algorithmic_bytes_per_launch")}})
                 del sfn, efn
                 torch.cuda.empty_cache()
             except Exception as e:  # informational runs: never lose the headline line over them

@@ -1,0 +1,49 @@
+#!/bin/bash
+# Collects the round's rocprofv3 evidence on a GPU box (run from the repo root: bash tools/collect_profiles.sh r02).
+# Output: gpurun_out/<tag>_profiles/ -- kernel-trace summaries (batch 1, batch 32, BASELINE configs[2]), the HBM traffic files
+# bench.py reads (tools/pmc_traffic.py; stamped with the kernel-source hash), matrix-core busy counters.  Counters are collected
+# in passes of their own with --kernel-trace only (MI355X_MICROARCH.md, HBM / rocprofv3 section).
+TAG=${1:-r02}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/${TAG}_profiles
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+COMMON="--no-cpu-baseline --no-extra --no-graph"
+W_B1="python $R/bench.py"
+W_B32="python $R/bench.py --batch 32"
+W_C3="python $R/bench.py --batch 64 --grid 64 --sample-steps 12"
+db() { find $1 -name "*.db" | head -1; }
+
+trace() {  # name, images, command...
+    local name=$1 images=$2; shift 2
+    rocprofv3 --kernel-trace --output-format rocpd -d $O/tmp_$name -- "$@" > $O/log_trace_$name.txt 2>&1
+    { echo "# rocprofv3 --kernel-trace --output-format rocpd -- $* ; python tools/prof_summary.py <db> $images   (MI355X)"; python $R/tools/prof_summary.py $(db $O/tmp_$name) $images; } > $O/${TAG}_kernel_trace_$name.txt 2>&1
+    rm -rf $O/tmp_$name
+}
+trace bench_b1_570m 6 $W_B1 --steps 4 --warmup 1 $COMMON
+trace bench_b32_570m 96 $W_B32 --steps 1 --warmup 1 $COMMON
+trace config3_b64_64x64 192 $W_C3 --steps 1 --warmup 1 $COMMON
+
+traffic() {  # name, batch grid sample_steps, command...
+    local name=$1 b=$2 g=$3 s=$4; shift 4
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format rocpd -d $O/tmp_f_$name -- "$@" > $O/log_pmc_fetch_$name.txt 2>&1
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format rocpd -d $O/tmp_w_$name -- "$@" > $O/log_pmc_write_$name.txt 2>&1
+    python $R/tools/pmc_traffic.py $O/tmp_f_$name $O/tmp_w_$name $O/${TAG}_pmc_traffic_$name.json $b $g $s > $O/log_pmc_traffic_$name.txt 2>&1
+    rm -rf $O/tmp_f_$name $O/tmp_w_$name
+}
+traffic b1 1 32 8 $W_B1 --steps 2 --warmup 1 $COMMON
+traffic b32 32 32 8 $W_B32 --steps 1 --warmup 1 $COMMON
+traffic config3 64 64 12 $W_C3 --steps 1 --warmup 0 $COMMON
+
+mfma() {  # name, command...
+    local name=$1; shift
+    rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --output-format rocpd -d $O/tmp_m_$name -- "$@" > $O/log_pmc_mfma_$name.txt 2>&1
+    { echo "# rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES -- $* ; python tools/pmc_summary.py <db> gemm_nt_kernel"
+      echo "# per-launch averages; matrix-core utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES)"
+      python $R/tools/pmc_summary.py $(db $O/tmp_m_$name) gemm_nt_kernel; } > $O/${TAG}_pmc_mfma_busy_$name.txt 2>&1
+    rm -rf $O/tmp_m_$name
+}
+mfma b1 $W_B1 --steps 2 --warmup 1 $COMMON
+mfma b32 $W_B32 --steps 1 --warmup 1 $COMMON
+mfma config3 $W_C3 --steps 1 --warmup 0 $COMMON
+ls -la $O

@@ -35,11 +35,14 @@ def counter_avg(path, counter, name_filter):
 
 def main():
     fetch_dir, write_dir, out = sys.argv[1:4]
+    # optional: batch grid sample_steps of the profiled bench.py command (default: the headline workload)
+    batch, grid, sample_steps = (int(v) for v in sys.argv[4:7]) if len(sys.argv) >= 7 else (1, 32, 8)
+    extra = "" if (batch, grid, sample_steps) == (1, 32, 8) else " --batch %d --grid %d --sample-steps %d" % (batch, grid, sample_steps)
     f_kb, n_f = counter_avg(fetch_dir, "FETCH_SIZE", "gemm_nt_kernel")
     w_kb, n_w = counter_avg(write_dir, "WRITE_SIZE", "gemm_nt_kernel")
     hbm = (2.0 * f_kb + w_kb) * 1024.0
-    j = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and a separate pass --pmc WRITE_SIZE) -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra --no-graph",
-         "workload": {"model": "570m", "batch_per_gpu": 1, "grid": 32, "sample_steps": 8},
+    j = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and a separate pass --pmc WRITE_SIZE) -- python bench.py%s --steps N --warmup 1 --no-cpu-baseline --no-extra --no-graph" % extra,
+         "workload": {"model": "570m", "batch_per_gpu": batch, "grid": grid, "sample_steps": sample_steps},
          "source_stamp": bench.source_stamp(), "stamped_sources": bench.TRAFFIC_SOURCES,
          "kernel": "gemm_nt_kernel (all instantiations)", "launches_profiled": n_f,
          "fetch_size_kb_avg_per_launch": round(f_kb, 2), "write_size_kb_avg_per_launch": round(w_kb, 2),
