@@ -50,6 +50,15 @@ __device__ __forceinline__ unsigned sk_owner(const SkPlan& p, unsigned x) {
     return x < big ? x / (p.q + 1) : p.r + (x - big) / p.q;
 }
 
+#ifdef PAELLA_GEMM_CLOCK_PROBE
+__device__ unsigned long long g_clock_probe[2];  // (shader cycles, 100 MHz wall-clock ticks) of one workgroup of the last launch
+extern "C" int paella_probe_gemm_clock(unsigned long long* out2) {
+    HIP_CHECK_RET(hipDeviceSynchronize());
+    HIP_CHECK_RET(hipMemcpyFromSymbol(out2, HIP_SYMBOL(g_clock_probe), 2 * sizeof(unsigned long long)));
+    return PAELLA_OK;
+}
+#endif
+
 template <int WM, int WN, int TM, int TN, int PD, int APRO, bool TAIL = false, int BK = 32>  // BK: K step (32 or 64 floats per LDS row); APRO: 0 none, 1 GRN scale/shift, 2 LayerNorm from row statistics; TAIL: fused sampling tail (head GEMM)
 // The 32x32 tile is the batch-1 workhorse and wants 5 workgroups per CU (1280 resident): ask for <= 96 VGPRs there.  Not for the
 // GRN-prologue variant (two more staged operands per unit): forced under 96 registers it spills inside the unit loop (measured
@@ -84,6 +93,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 &
     const unsigned u0 = sk_start(p, gid);
     const int n = (int)(p.q + (gid < p.r ? 1u : 0u));
     if (n <= 0) return;  // host keeps G <= U, so every workgroup owns at least one unit
+#ifdef PAELLA_GEMM_CLOCK_PROBE  // tools/probes/gemm_clock_probe.py builds its own library with this: shader clock the launch really ran at
+    const unsigned long long cp_t0 = __builtin_readcyclecounter(), cp_w0 = wall_clock64();
+#endif
     const int KT = p.KT;
 
     const int tid = threadIdx.x;
@@ -240,6 +252,40 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 &
             const int row = ldrow + i * RP;
             if (LB * RP == BN || row < BN) *reinterpret_cast<f32x4*>(Bs + row * BK + ((ldc4 ^ (row & (SL - 1))) << 2)) = r.b[i];
         }
+    };
+    // The 8-wave 128x128 tiles run one workgroup per CU, two waves per SIMD in lock step: with "store, barrier, read all fragments,
+    // multiply" the LDS store phase and the fragment-read latency idle the matrix cores for ~25 % of the launch
+    // (profiles/r02_pmc_mfma_busy_config3.txt).  PIPE splits a unit's MFMA block around the LDS hand-over instead:
+    //   read this unit's second-k-group fragments | MFMA k-group 0 | MFMA half of k-group 1 | store the next unit's tile, barrier |
+    //   read the NEXT unit's first-k-group fragments | MFMA rest of k-group 1
+    // so every ds_read runs under MFMAs that do not need it and the store sits between two MFMA runs; same 48 fragment registers.
+    constexpr bool PIPE = (NW == 8 && PD == 1 && TM * TN == 8 && BK == 32 && !TAIL);
+    f32x4 Fa[KG][TM], Fb[KG][TN];  // PIPE only: fragments by k group; group 0 belongs to the unit ahead during a unit's last quarter
+    auto read_group = [&](auto kk_tag, int slot) __attribute__((always_inline)) {
+        constexpr int kk = decltype(kk_tag)::value;
+        const float* As = smem + slot * TILE_FLOATS;
+        const float* Bs = As + BM * BK;
+        const int c4 = kk * 4 + kq;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row = (wm * TM + i) * 16 + r16;
+            Fa[kk][i] = *reinterpret_cast<const f32x4*>(As + row * BK + ((c4 ^ (row & (SL - 1))) << 2));
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int row = (wn * TN + j) * 16 + r16;
+            Fb[kk][j] = *reinterpret_cast<const f32x4*>(Bs + row * BK + ((c4 ^ (row & (SL - 1))) << 2));
+        }
+    };
+    auto mfma_group = [&](auto kk_tag, auto e0_tag, auto e1_tag) __attribute__((always_inline)) {
+        constexpr int kk = decltype(kk_tag)::value, e0 = decltype(e0_tag)::value, e1 = decltype(e1_tag)::value;
+#pragma unroll
+        for (int e = e0; e < e1; ++e)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(Fb[kk][j][e], Fa[kk][i][e], acc[i][j], 0, 0, 0);
     };
     // A 1x1 wave tile alternates two accumulators so its MFMAs are never back-to-back dependent
     // (v_mfma_f32_16x16x4_f32: 32-cycle issue, 40-cycle dependent latency).
@@ -491,6 +537,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 &
     for (int j = 0; j < PD; ++j) fetch(R[j]);
     store_unit(R[0], 0);
     __syncthreads();
+    if constexpr (PIPE) read_group(std::integral_constant<int, 0>{}, 0);
 
     int ctile = (int)(u0 / (unsigned)KT);
     int ckt = (int)(u0 - (unsigned)ctile * (unsigned)KT);
@@ -498,13 +545,32 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 &
     int slot = 0;
     // one unit: `rf` is the free ring stage (gets the unit PD ahead), `rs` holds the next unit (goes to the other LDS stage).
     // One basic block per phase: the prefetch is pinned above the MFMA block (hipcc sinks it otherwise).
-    auto step = [&](Stage& rf, const Stage& rs, int sl) __attribute__((always_inline)) {
+    auto step = [&](Stage& rf, const Stage& rs, auto sl_tag) __attribute__((always_inline)) {
+        constexpr int sl = decltype(sl_tag)::value;
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        using I4 = std::integral_constant<int, 4>;
         fetch(rf);
         __builtin_amdgcn_sched_barrier(0);
-        compute(sl);
-        __builtin_amdgcn_sched_barrier(0);
-        store_unit(rs, sl ^ 1);
-        __syncthreads();
+        if constexpr (PIPE) {
+            read_group(I1{}, sl);  // k group 1 of this unit; group 0 was read behind the previous barrier
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_group(I0{}, I0{}, I4{});
+            mfma_group(I1{}, I0{}, I2{});
+            __builtin_amdgcn_sched_barrier(0);
+            store_unit(rs, sl ^ 1);
+            __syncthreads();
+            read_group(I0{}, sl ^ 1);  // k group 0 of the next unit
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_group(I1{}, I2{}, I4{});
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            compute(sl);
+            __builtin_amdgcn_sched_barrier(0);
+            store_unit(rs, sl ^ 1);
+            __syncthreads();
+        }
     };
     // A segment's units with COMPILE-TIME LDS stages and ring roles (immediate LDS offsets, statically indexed register stages):
     // two instantiations, by the LDS stage the segment starts in.  A segment of odd length leaves the ring in phase 1, so it is
@@ -514,17 +580,17 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 &
         int s = 0;
         if constexpr (PD == 1) {
             for (; s + 2 <= len; s += 2) {
-                step(R[0], R[0], S0);
-                step(R[0], R[0], S0 ^ 1);
+                step(R[0], R[0], std::integral_constant<int, S0>{});
+                step(R[0], R[0], std::integral_constant<int, S0 ^ 1>{});
             }
-            if (s < len) step(R[0], R[0], S0);
+            if (s < len) step(R[0], R[0], std::integral_constant<int, S0>{});
         } else {
             for (; s + 2 <= len; s += 2) {
-                step(R[0], R[1], S0);
-                step(R[1], R[0], S0 ^ 1);
+                step(R[0], R[1], std::integral_constant<int, S0>{});
+                step(R[1], R[0], std::integral_constant<int, S0 ^ 1>{});
             }
             if (s < len) {
-                step(R[0], R[1], S0);
+                step(R[0], R[1], std::integral_constant<int, S0>{});
                 R[1] = R[0];
             }
         }
@@ -540,6 +606,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 &
         ckt += seg_len;
         if (ckt == KT) { ckt = 0; ++ctile; }
     }
+#ifdef PAELLA_GEMM_CLOCK_PROBE
+    if (gid == (G >> 1) && tid == 0) {  // a workgroup from the middle of the launch
+        g_clock_probe[0] = __builtin_readcyclecounter() - cp_t0;
+        g_clock_probe[1] = wall_clock64() - cp_w0;
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------

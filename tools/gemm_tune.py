@@ -79,7 +79,7 @@ def main():
                    9: (128, 128), 10: (128, 128), 11: (128, 32), 12: (128, 64), 13: (64, 64), 14: (128, 64), 15: (256, 32), 16: (256, 64),
                    17: (128, 64), 18: (64, 64), 19: (32, 32), 20: (128, 64), 21: (64, 32), 22: (32, 128), 23: (32, 64),
                    24: (32, 32), 25: (32, 32), 26: (64, 64), 27: (128, 32), 28: (32, 64), 29: (128, 64)}
-        bk_of = {c: (64 if c >= 24 else 32) for c in tile_of}
+        bk_of = {c: (64 if 24 <= c <= 29 else 32) for c in tile_of}
         def fits(c):  # skip tiles that waste more than half their rows on this M
             bm = tile_of[c][0]
             return bm <= 2 * max(M, 16) or c in (2, 5)
