@@ -23,6 +23,8 @@ trace() {  # name, images, command...
 trace bench_b1_570m 6 $W_B1 --steps 4 --warmup 1 $COMMON
 trace bench_b32_570m 96 $W_B32 --steps 1 --warmup 1 $COMMON
 trace config3_b64_64x64 192 $W_C3 --steps 1 --warmup 1 $COMMON
+# BASELINE configs[4] per-GPU share (1B model, 1024 px = 128x128 tokens, batch 16, S = 264: encode -> masked renoise -> 2 sampling steps -> decode)
+trace config5_b16_128x128_inpaint_test 16 env PYTHONPATH=$R python -m pytest $R/tests/test_gpu_sample.py --rootdir $R -q -p no:cacheprovider -k config5_full_size
 
 traffic() {  # name, batch grid sample_steps, command...
     local name=$1 b=$2 g=$3 s=$4; shift 4
