@@ -207,11 +207,13 @@ __global__ __launch_bounds__(256) void grn_finalize_kernel(const float* __restri
 // mean and writes scale[b][c] = 1 + gamma[c] * Gx / (mean + 1e-6).  Replaces the two-pass kernels above on the
 // per-step path (no re-read of the 4c-wide hidden tensor).
 template <int G>  // G > 0: compile-time group count (all loads of a channel quad in flight together); 0 = runtime
-__global__ __launch_bounds__(256) void grn_from_partials_kernel(const float* __restrict__ part, const float* __restrict__ gamma,
-                                                                float* __restrict__ scale, int groups_rt, int C) {
-    // grid (ceil(C/1024), B): every workgroup recomputes the sample's channel mean (tiny, L2-resident, identical
-    // fixed-order arithmetic in every workgroup -> deterministic) and then writes the scale of its own 1024 channels.
-    __shared__ float red[256];
+__global__ __launch_bounds__(1024) void grn_from_partials_kernel(const float* __restrict__ part, const float* __restrict__ gamma,
+                                                                 float* __restrict__ scale, int groups_rt, int C) {
+    // grid (ceil(C/4096), B), 1024 threads: every workgroup recomputes the sample's channel mean (tiny, L2-resident, identical
+    // fixed-order arithmetic in every workgroup -> deterministic) and then writes the scale of its own 4096 channels.  The launch
+    // sits between the two GEMMs of every MLP block (256 times per image at batch 1), so it is built for latency: at most two
+    // dependent load rounds per thread (C <= 8192), one shuffle tree, one barrier.
+    __shared__ float red[16];
     const int groups = G > 0 ? G : groups_rt;
     const int b = blockIdx.y;
     const int C4 = C >> 2;
@@ -231,19 +233,20 @@ __global__ __launch_bounds__(256) void grn_from_partials_kernel(const float* __r
     };
     float s = 0.f;
     f32x4 mine = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int my_c4 = blockIdx.x * 256 + threadIdx.x;
-    for (int c4 = threadIdx.x; c4 < C4; c4 += 256) {
+    const int my_c4 = blockIdx.x * 1024 + threadIdx.x;
+    for (int c4 = threadIdx.x; c4 < C4; c4 += 1024) {
         const f32x4 q = colsum(c4);
         if (c4 == my_c4) mine = q;
         s += (sqrtf(q[0]) + sqrtf(q[1])) + (sqrtf(q[2]) + sqrtf(q[3]));
     }
-    red[threadIdx.x] = s;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-        __syncthreads();
-    }
-    const float denom = red[0] / (float)C + 1e-6f;
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) tot += red[w];  // fixed wave order
+    const float denom = tot / (float)C + 1e-6f;
     if (my_c4 < C4) {
         const f32x4 gm = ld4(gamma + my_c4 * 4);
         f32x4 o;
@@ -256,7 +259,7 @@ __global__ __launch_bounds__(256) void grn_from_partials_kernel(const float* __r
 int launch_grn_from_partials(const float* part, const float* gamma, float* scale, int B, int groups, int C, hipStream_t st) {
     if (B <= 0) return PAELLA_OK;
     if (C & 3) { paella_set_error("grn: C %% 4 != 0"); return PAELLA_ERR_ARG; }
-    const dim3 grid((C / 4 + 255) / 256, B), block(256);
+    const dim3 grid((C / 4 + 1023) / 1024, B), block(1024);
     switch (groups) {
         case 1: hipLaunchKernelGGL((grn_from_partials_kernel<1>), grid, block, 0, st, part, gamma, scale, groups, C); break;
         case 4: hipLaunchKernelGGL((grn_from_partials_kernel<4>), grid, block, 0, st, part, gamma, scale, groups, C); break;
