@@ -15,8 +15,9 @@ With N GPUs every rank generates its own batch (weak scaling); rank 0 owns the c
 broadcasts it once per step over RCCL (the only collective of the path).
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).  Besides the contract fields the line carries
-`throughput`: the same path at throughput batch sizes (batch 32 at configs[1]; BASELINE configs[2] = batch 64, 64x64 tokens,
-12 steps), each with its own in-run roofline.
+`throughput`: the same path at throughput batch sizes, each with its own in-run roofline -- on one GPU batch 32 at configs[1] and
+BASELINE configs[2] (batch 64, 64x64 tokens, 12 steps); on N GPUs batch 32 PER GPU through the same broadcast + shard path
+(whole-node images/s, max-over-ranks timing).
 """
 import argparse
 import ctypes
@@ -301,27 +302,59 @@ def main():
     if distributed:
         dist.barrier()
 
-    # ---- the same path at throughput batch sizes (rank 0, single GPU only): each with its own in-run roofline ----
+    # ---- the same path at throughput batch sizes, each with its own in-run roofline.  One GPU: batch 32 at configs[1] and BASELINE
+    # configs[2].  N GPUs: batch 32 PER GPU through the same broadcast + shard path (whole-node images/s, max-over-ranks timing). ----
     throughput = None
-    if rank == 0 and not a.no_extra and not distributed and a.model == "570m" and (a.batch, a.grid, a.sample_steps) == (1, 32, 8):
+    if not a.no_extra and a.model == "570m" and (a.batch, a.grid, a.sample_steps) == (1, 32, 8):
         throughput = []
-        for (eb, eg, es, k, w) in [(32, 32, 8, 3, 1), (64, 64, 12, 2, 1)]:
-            try:
-                ce, ue = mk_cond(eb, 2), mk_cond(eb, 3)
+        for (eb, eg, es, k, w) in ([(32, 32, 8, 3, 1), (64, 64, 12, 2, 1)] if not distributed else [(32, 32, 8, 3, 1)]):
+            err = None
+            sfn = efn = None
+            try:  # local set-up only (no collectives): capture the graph for these shapes
+                tot_e = eb * world
+                ce_all = ue_all = None
+                if rank == 0:
+                    ce_all, ue_all = mk_cond(tot_e, 2), mk_cond(tot_e, 3)
+                lo_e, hi_e = shard_bounds(tot_e, rank, world)
+                tm_e = mk_cond(tot_e, 2)
+                lay_e = conditioning_layout([tm_e, tm_e]) if distributed else None
                 sfn, efn = make_runner(eb, eg, es, 50000 * eb)
-                dte = timed(lambda: sfn(ce, ue), k, w, False, device)
-                r = gemm_roofline(lib, lambda: efn(ce, ue), device, a.model, eb, eg, es, a.gemm, True)
+            except Exception as e:  # informational runs: never lose the headline line over them
+                err = repr(e)
+            if distributed:  # every rank must be ready before the first collective of the extra run
+                flag = torch.tensor([0 if err else 1], device=device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag.item()) == 0 and err is None:
+                    err = "set-up failed on another rank"
+            if err is not None:
+                throughput.append({"batch": eb, "grid": eg, "sample_steps": es, "error": err})
+                continue
+
+            def estep():
+                if distributed:
+                    c, u = broadcast_conditioning([ce_all, ue_all] if rank == 0 else None, src=0, device=device, layout=lay_e)
+                    c, u = shard_inputs(c, lo_e, hi_e), shard_inputs(u, lo_e, hi_e)
+                else:
+                    c, u = ce_all, ue_all
+                return sfn(c, u)
+
+            dte = timed(estep, k, w, distributed, device)
+            if rank == 0:
+                c0e, u0e = (ce_all, ue_all) if not distributed else (shard_inputs(ce_all, lo_e, hi_e), shard_inputs(ue_all, lo_e, hi_e))
+                r = gemm_roofline(lib, lambda: efn(c0e, u0e), device, a.model, eb, eg, es, a.gemm, True)
                 throughput.append({"workload": "%s: batch %d per GPU, %dx%d tokens, %d steps, CFG 8.0, + VQGAN f8 decode"
                                                % (WORKLOAD_TAG.get((a.model, eb, eg, es), "configs[1] model at a throughput batch"), eb, eg, eg, es),
-                                   "batch": eb, "grid": eg, "sample_steps": es, "steps": k, "warmup": w,
-                                   "images_per_sec": round(eb * k / dte, 3), "ms_per_image": round(dte / (eb * k) * 1e3, 3),
+                                   "batch": eb, "n_gpus": world, "global_batch": tot_e, "grid": eg, "sample_steps": es, "steps": k, "warmup": w,
+                                   "images_per_sec": round(tot_e * k / dte, 3), "ms_per_image": round(dte / (tot_e * k) * 1e3, 3),
                                    "roofline": {kk: r[kk] for kk in ("bound", "achieved", "peak", "unit", "frac", "executed_tflops", "executed_frac",
                                                                       "launches_per_step", "avg_launch_us", "gemm_ms_per_step", "traffic", "traffic_source",
                                                                       "algorithmic_bytes_per_launch")}})
-                del sfn, efn
-                torch.cuda.empty_cache()
-            except Exception as e:  # informational runs: never lose the headline line over them
-                throughput.append({"batch": eb, "grid": eg, "sample_steps": es, "error": repr(e)})
+            if distributed:
+                dist.barrier()
+            del sfn, efn
+            torch.cuda.empty_cache()
+        if rank != 0:
+            throughput = None
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:  # the CPU baseline is an N = 1 figure
