@@ -50,6 +50,14 @@ __device__ __forceinline__ unsigned sk_owner(const SkPlan& p, unsigned x) {
     return x < big ? x / (p.q + 1) : p.r + (x - big) / p.q;
 }
 
+// buffer_load_dwordx4 ... offen lds: 64 lanes x 16 bytes from (descriptor + per-lane offset + uniform offset) straight into LDS at
+// lds_wave_base + lane * 16 (the base travels in M0, so it must be wave-uniform).  Device pass only: the host pass has no LDS address space.
+__device__ __forceinline__ void dma_b128_to_lds(__amdgpu_buffer_rsrc_t rsrc, float* lds_wave_base, unsigned voffset, int soffset) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voffset, soffset, 0, 0);
+#endif
+}
+
 #ifdef PAELLA_GEMM_CLOCK_PROBE
 __device__ unsigned long long g_clock_probe[2];  // (shader cycles, 100 MHz wall-clock ticks) of one workgroup of the last launch
 extern "C" int paella_probe_gemm_clock(unsigned long long* out2) {
@@ -59,7 +67,8 @@ extern "C" int paella_probe_gemm_clock(unsigned long long* out2) {
 }
 #endif
 
-template <int WM, int WN, int TM, int TN, int PD, int APRO, bool TAIL = false, int BK = 32>  // BK: K step (32 or 64 floats per LDS row); APRO: 0 none, 1 GRN scale/shift, 2 LayerNorm from row statistics; TAIL: fused sampling tail (head GEMM)
+template <int WM, int WN, int TM, int TN, int PD, int APRO, bool TAIL = false, int BK = 32, bool DMA = false>  // BK: K step (32 or 64 floats per LDS row); APRO: 0 none, 1 GRN scale/shift, 2 LayerNorm from row statistics; TAIL: fused sampling tail (head GEMM);
+// DMA: operands that need no transform (W always, A when APRO == 0) go global -> LDS directly (buffer_load ... lds), no staging registers, no ds_write pass
 // The 32x32 tile is the batch-1 workhorse and wants 5 workgroups per CU (1280 resident): ask for <= 96 VGPRs there.  Not for the
 // GRN-prologue variant (two more staged operands per unit): forced under 96 registers it spills inside the unit loop (measured
 // 33 us instead of 25 for 128x1280x5120), so it runs 4 workgroups per CU and the heuristic gives it at most 1024 workgroups.
@@ -77,6 +86,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 &
     static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
     static_assert(PD == 1 || PD == 2, "prefetch ring depth 1 or 2");
     static_assert(BK == 32 || BK == 64, "K step of 32 or 64");
+    // Direct-to-LDS operands: one buffer_load_dwordx4 ... lds per wave and 8 tile rows writes 1 KiB at M0 + lane * 16, i.e. LDS stays
+    // lane-linear; the XOR swizzle of the 16-byte slots is applied to the SOURCE address instead (lane l of a row fetches chunk
+    // (l % 8) ^ (row % 8)).  Needs K % BK == 0 (no activation-side K-tail mask) -- the host picks the register-staged twin otherwise.
+    constexpr bool DMA_W = DMA, DMA_A = DMA && APRO == 0;
+    static_assert(!DMA || (PD == 1 && BK == 32 && !TAIL && (BM * SL) % NT == 0 && (BN * SL) % NT == 0), "DMA variant: 1-deep, K step 32, whole passes");
     // one LDS object: two tile stages + 16 floats for the ticket broadcast (the NEXT unit's tile is already staged when a
     // segment is flushed, so the flag cannot live inside the stages)
     constexpr int TAIL_FLOATS = TAIL ? BM * WN * 2 : 0;  // fused tail: per row and wave column, the best (score, label)
@@ -179,12 +193,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 &
                 cx[i] = xo * g.cv.stride;
                 aoff[i] = (unsigned)(bimg - img0) * (unsigned)(g.cv.Hi * g.cv.Wi);  // position index of the image's (0, 0), relative to the tile's first image
             } else {
-                aoff[i] = ((unsigned)(gmc - m0) * (unsigned)g.lda + (unsigned)(ldc4 * 4)) * 4u;
+                aoff[i] = ((unsigned)(gmc - m0) * (unsigned)g.lda + (unsigned)((DMA_A ? (ldc4 ^ (ldrow & (SL - 1))) : ldc4) * 4)) * 4u;
             }
             if (APRO == 1) soff[i] = ((unsigned)(gmc / g.a_rows_per_sample - smp0) * (unsigned)g.K + (unsigned)(ldc4 * 4)) * 4u;
         }
 #pragma unroll
-        for (int i = 0; i < LB; ++i) boff[i] = ((unsigned)(min(n0 + ldrow + i * RP, g.N - 1) - n0) * (unsigned)g.ldw + (unsigned)(ldc4 * 4)) * 4u;
+        for (int i = 0; i < LB; ++i) boff[i] = ((unsigned)(min(n0 + ldrow + i * RP, g.N - 1) - n0) * (unsigned)g.ldw + (unsigned)((DMA_W ? (ldc4 ^ (ldrow & (SL - 1))) : ldc4) * 4)) * 4u;
     };
     set_tile(ltile);
     if (APRO == 3) {
@@ -211,7 +225,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 &
         }
     }
 
-    auto load_unit = [&](Stage& r) __attribute__((always_inline)) {  // loads the unit under the load cursor
+    auto load_unit = [&](Stage& r, int dma_slot) __attribute__((always_inline)) {  // loads the unit under the load cursor (DMA operands: into LDS stage dma_slot)
+        float* dAs = smem + dma_slot * TILE_FLOATS + (wave * (64 / SL)) * BK;  // this wave's first row group of the stage (wave-uniform -> M0)
+        float* dBs = dAs + BM * BK;
         const int kofs = lkt * (BK * 4);  // uniform byte offset of this K step -> the loads' SGPR offset
         int oy = 0, ox = 0;
         if (APRO == 3) {
@@ -225,6 +241,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 &
                 r.ok[i] = (unsigned)yy < (unsigned)g.cv.Hi && (unsigned)xx < (unsigned)g.cv.Wi;
                 const unsigned pos = aoff[i] + (unsigned)(min(max(yy, 0), g.cv.Hi - 1) * g.cv.Wi + min(max(xx, 0), g.cv.Wi - 1));
                 r.a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcA, (pos * (unsigned)g.cv.C + (unsigned)(ldc4 * 4)) * 4u, lc0 * 4, 0));
+            } else if (DMA_A) {
+                dma_b128_to_lds(rsrcA, dAs + i * RP * BK, aoff[i], kofs);
             } else {
                 r.a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcA, aoff[i], kofs, 0));
             }
@@ -232,14 +250,17 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 &
         }
         if (APRO == 1) r.t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcT, (unsigned)(ldc4 * 16), kofs, 0));
 #pragma unroll
-        for (int i = 0; i < LB; ++i) r.b[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcW, boff[i], kofs, 0));
+        for (int i = 0; i < LB; ++i) {
+            if (DMA_W) dma_b128_to_lds(rsrcW, dBs + i * RP * BK, boff[i], kofs);
+            else r.b[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcW, boff[i], kofs, 0));
+        }
         r.kok = lkt * BK + ldc4 * 4 < g.K;
     };
     auto store_unit = [&](const Stage& r, int slot) __attribute__((always_inline)) {
         float* As = smem + slot * TILE_FLOATS;
         float* Bs = As + BM * BK;
 #pragma unroll
-        for (int i = 0; i < LA; ++i) {
+        for (int i = 0; i < (DMA_A ? 0 : LA); ++i) {
             const int row = ldrow + i * RP;
             f32x4 v = r.a[i];
             if (APRO == 1) v = v * r.s[i] + r.t;
@@ -248,10 +269,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 &
             if (LA * RP == BM || row < BM) *reinterpret_cast<f32x4*>(As + row * BK + ((ldc4 ^ (row & (SL - 1))) << 2)) = v;
         }
 #pragma unroll
-        for (int i = 0; i < LB; ++i) {
+        for (int i = 0; i < (DMA_W ? 0 : LB); ++i) {
             const int row = ldrow + i * RP;
             if (LB * RP == BN || row < BN) *reinterpret_cast<f32x4*>(Bs + row * BK + ((ldc4 ^ (row & (SL - 1))) << 2)) = r.b[i];
         }
+        if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA'd part of the stage has landed before the barrier that publishes it
     };
     // The 8-wave 128x128 tiles run one workgroup per CU, two waves per SIMD in lock step: with "store, barrier, read all fragments,
     // multiply" the LDS store phase and the fragment-read latency idle the matrix cores for ~25 % of the launch
@@ -520,8 +542,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 &
     // ---- the unit stream ----
     // invariant at the top of unit i: unit i is in LDS[slot]; R[(i+1)%PD .. (i+PD-1)%PD] hold units i+1..i+PD-1; R[i%PD] is free
     int loaded = 0;  // units fetched so far; the load cursor stops on the range's last unit (re-reading it hits L1/L2)
-    auto fetch = [&](Stage& r) __attribute__((always_inline)) {
-        load_unit(r);
+    auto fetch = [&](Stage& r, int dma_slot) __attribute__((always_inline)) {
+        load_unit(r, dma_slot);
         if (++loaded < n) {  // workgroup-uniform; never runs into the next workgroup's units
             if (APRO == 3 && (lc0 += BK) == g.cv.C) { lc0 = 0; ++ltap; }
             if (++lkt == KT) {
@@ -534,7 +556,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 &
         }
     };
 #pragma unroll
-    for (int j = 0; j < PD; ++j) fetch(R[j]);
+    for (int j = 0; j < PD; ++j) fetch(R[j], 0);  // (DMA variants are 1-deep: unit 0 goes straight to LDS stage 0)
     store_unit(R[0], 0);
     __syncthreads();
     if constexpr (PIPE) read_group(std::integral_constant<int, 0>{}, 0);
@@ -551,7 +573,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 &
         using I1 = std::integral_constant<int, 1>;
         using I2 = std::integral_constant<int, 2>;
         using I4 = std::integral_constant<int, 4>;
-        fetch(rf);
+        fetch(rf, sl ^ 1);  // DMA operands of the next unit start landing in the other LDS stage now (last read before the previous barrier)
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (PIPE) {
             read_group(I1{}, sl);  // k group 1 of this unit; group 0 was read behind the previous barrier
@@ -661,9 +683,30 @@ static constexpr bool conv_tile() {
 }
 static bool conv_cfg(int cfg) { return cfg == 2 || cfg == 5 || cfg == 9 || cfg == 10 || cfg == 14 || cfg == 18 || cfg == 19; }
 
+// tile configs that carry the direct-to-LDS (DMA) twin: the two large-problem workhorses (ids 10 and 18)
+template <int WM, int WN, int TM, int TN, int PD, int BK>
+static constexpr bool dma_tile() {
+    return BK == 32 && PD == 1 && ((WM == 2 && WN == 4 && TM == 4 && TN == 2) || (WM == 2 && WN == 2 && TM == 2 && TN == 2));
+}
+static int g_gemm_dma = 1;  // test hook (test_hooks.h): 0 = always the register-staged kernels
+extern "C" int paella_test_gemm_dma(int on) { g_gemm_dma = on != 0; return PAELLA_OK; }
+
 template <int WM, int WN, int TM, int TN, int PD, int BK>
 static void launch_one(const GemmArgs& g, const SkPlan& p, unsigned G, float* slabs, unsigned* tickets, unsigned slab_bytes, hipStream_t st) {
     constexpr int NT = 64 * WM * WN;
+    if constexpr (dma_tile<WM, WN, TM, TN, PD, BK>()) {
+        if (g_gemm_dma && g.K % BK == 0) {  // no K tail: operands without a transform go global -> LDS directly
+            if (g.cv.enabled)
+                hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, PD, 3, false, BK, true>), dim3(G), dim3(NT), 0, st, g, p, slabs, tickets, slab_bytes);
+            else if (g.a_scale)
+                hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, PD, 1, false, BK, true>), dim3(G), dim3(NT), 0, st, g, p, slabs, tickets, slab_bytes);
+            else if (g.ln_stats)
+                hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, PD, 2, false, BK, true>), dim3(G), dim3(NT), 0, st, g, p, slabs, tickets, slab_bytes);
+            else
+                hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, PD, 0, false, BK, true>), dim3(G), dim3(NT), 0, st, g, p, slabs, tickets, slab_bytes);
+            return;
+        }
+    }
     if constexpr (conv_tile<WM, WN, TM, TN, PD, BK>()) {
         if (g.cv.enabled) {
             hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, PD, 3, false, BK>), dim3(G), dim3(NT), 0, st, g, p, slabs, tickets, slab_bytes);
@@ -683,14 +726,15 @@ static inline long tiles_of_cfg(int c, int M, int N) {
     return (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
 }
 
-// Tile / workgroup-count choice, fitted to tools/gemm_tune.py sweeps on MI355X (profiles/r02_gemm_tile_sweep*.txt).
+// Tile / workgroup-count choice, fitted to tools/gemm_tune.py sweeps on MI355X (profiles/r02_gemm_tile_sweep*.txt,
+// profiles/r02_gemm_midsize_sweep_by_prologue.txt, profiles/r02_gemm_dma_sweep.txt).
 // Returns the tile config and G (number of workgroups = number of contiguous unit ranges).  What the sweeps show:
-//  * >= 1024 tiles of 128x128: one tile per workgroup, 8 waves (cfg 10): 124-133 TFLOP/s at any K;
-//  * fewer 128-tiles but >= 2.4 GFLOP (the batched mid-size shapes, e.g. 4096x1280x1280, 1024x1280x5120, 4096x640x2560): 64x64
-//    tiles with a 1-deep ring (cfg 18: 4 workgroups per CU resident, 3 with the LayerNorm prologue) -- one tile per workgroup when
-//    there are >= 2048 of them, else every resident slot gets one balanced range of (tile, K-step) units.  Within 5 % of the best
-//    variant on every shape swept and 10-15 % ahead of 128x128 tiles in 512 ranges (which run as two rounds: that tile holds one
-//    workgroup per CU);
+//  * >= 1024 tiles of 128x128: one tile per workgroup, 8 waves (cfg 10, direct-to-LDS operands): 126-135 TFLOP/s;
+//  * fewer 128-tiles but >= 5 GFLOP (the batched mid-size shapes, e.g. 4096x1280x1280, 1024x1280x5120, 16384x640x2560): the same
+//    tile as ONE persistent workgroup per CU (G = 256 balanced ranges of (tile, K-step) units) -- best or within 1 % of the best
+//    variant on every shape swept, 2-5 % ahead of 64x64 tiles when K is long; short K (<= 768) with >= 1024 64x64 tiles: one of
+//    those per workgroup (cfg 18);
+//  * 2.4-5 GFLOP (1024x1280x1280): 64x64 tiles on 512 balanced ranges;
 //  * skinny batch-1 shapes: 32x32 tiles, ~10 K-steps per workgroup, at most 1280 workgroups = 5 per CU, all resident at once
 //    (__launch_bounds__(256, 5) on that instantiation guarantees the registers for it) -- every larger
 //    tile lands within 5 % of it (24-27 us for 128x5120x1280): these launches are bound by ramp + combine, not by the tile.
@@ -701,10 +745,12 @@ static void choose_config(int M, int N, int K, int apro, size_t slab_cap_bytes, 
     int cfg;
     long G;
     if (T128 >= 1024) { cfg = 10; G = T128; }
-    else if (macs >= 1.2e9 || T64 >= 1024) {
+    else if (macs >= 2.5e9) {
+        if (K <= 768 && T64 >= 1024) { cfg = 18; G = T64; }
+        else { cfg = 10; G = 256; }
+    } else if (macs >= 1.2e9 || T64 >= 1024) {
         cfg = 18;
-        const long resident = apro == 2 ? 768 : 1024;
-        G = (T64 >= 2048 || ktiles < 16) ? T64 : resident;  // short K: ranges would be mostly partial tiles
+        G = (T64 >= 2048 || ktiles < 16) ? T64 : 512;  // short K: ranges would be mostly partial tiles
     } else {
         cfg = 5;
         const long U = T32 * ktiles;

@@ -17,6 +17,8 @@ int paella_test_attention_variant(int v);
  * squares) (LayerNorm folded into the consumer) */
 int paella_test_gemm_prologue(const float* A, const float* W, float* C, int M, int N, int K, int mode, const float* scale, const float* shift,
                               int rows_per_sample, const float* ln_stats, int tile_cfg, int splitk, void* ws, size_t ws_bytes, void* stream);
+/* 0 = never use the direct-to-LDS (DMA) twins of the large GEMM tiles (A/B and parity checks); 1 = default */
+int paella_test_gemm_dma(int on);
 #ifdef __cplusplus
 }
 #endif

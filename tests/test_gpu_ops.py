@@ -100,6 +100,39 @@ def test_gemm_operand_prologues_every_tile_config(lib, cfg, mode, splitk):
     np.testing.assert_allclose(C.cpu().numpy(), ref.numpy(), atol=2e-4, rtol=2e-5)
 
 
+@pytest.mark.parametrize("cfg", [10, 18])
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("splitk", [1, -96])
+def test_gemm_direct_to_lds_twin_is_bit_identical(lib, cfg, mode, splitk):
+    """The large tiles have a twin that moves untransformed operands global -> LDS directly (buffer_load ... lds, swizzle applied to the
+    source address).  Same LDS image, same MFMA order: the result must equal the register-staged kernel's bit for bit (test hook
+    switches the twin off), on ragged M / N and with partial tiles combined in-launch."""
+    rps, B, N, K = 24, 23, 328, 416  # K % 32 == 0 (the twin's precondition), M = 552
+    M = rps * B
+    g = torch.Generator().manual_seed(cfg * 7 + mode * 3 + abs(splitk))
+    A = torch.randn(M, K, generator=g) + torch.arange(K)[None, :] * 0.01
+    W = torch.randn(N, K, generator=g) / K ** 0.5 + torch.arange(N)[:, None] * 0.002
+    scale, shift = 1.0 + 0.3 * torch.randn(B, K, generator=g), 0.2 * torch.randn(K, generator=g)
+    blk = A.view(M, K // 16, 16)
+    stats = torch.stack([blk.sum(-1), (blk * blk).sum(-1)], dim=-1).contiguous()
+    Ad, Wd, sc, sh, sd = A.cuda(), W.cuda(), scale.cuda(), shift.cuda(), stats.cuda()
+    ws = _lib.new_workspace(64 << 20, "cuda")
+    outs = []
+    for dma in (1, 0):
+        lib.paella_test_gemm_dma(dma)
+        try:
+            C = torch.full((M, N), float("nan"), device="cuda")
+            _check(lib, lib.paella_test_gemm_prologue(_p(Ad), _p(Wd), _p(C), M, N, K, mode, _p(sc), _p(sh), rps, _p(sd), cfg, splitk, _p(ws), ws.numel(), _st()))
+            torch.cuda.synchronize()
+        finally:
+            lib.paella_test_gemm_dma(1)
+        outs.append(C)
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1])
+    a2 = A.double() if mode == 0 else (A.double() * scale.double().repeat_interleave(rps, dim=0) + shift.double() if mode == 1 else F.layer_norm(A.double(), (K,), None, None, 1e-6))
+    np.testing.assert_allclose(outs[0].cpu().numpy(), (a2 @ W.double().t()).float().numpy(), atol=1e-3, rtol=2e-5)
+
+
 @pytest.mark.parametrize("cfg,G", [(5, 512), (11, 512), (12, 256), (12, 509), (13, 768), (14, 256), (16, 256), (22, 640), (9, 300), (2, 1000), (24, 512), (25, 777), (26, 100), (29, 64)])
 def test_gemm_stream_k_is_repeatable(lib, cfg, G):
     """Balanced unit ranges (partial tiles combined by the last arriver in fixed part order): many back-to-back launches on
