@@ -683,10 +683,10 @@ static constexpr bool conv_tile() {
 }
 static bool conv_cfg(int cfg) { return cfg == 2 || cfg == 5 || cfg == 9 || cfg == 10 || cfg == 14 || cfg == 18 || cfg == 19; }
 
-// tile configs that carry the direct-to-LDS (DMA) twin: the two large-problem workhorses (ids 10 and 18)
+// tile configs that carry the direct-to-LDS (DMA) twin: the two large-problem workhorses (ids 10 and 18) and the 1-deep 32x32 tile (id 19)
 template <int WM, int WN, int TM, int TN, int PD, int BK>
 static constexpr bool dma_tile() {
-    return BK == 32 && PD == 1 && ((WM == 2 && WN == 4 && TM == 4 && TN == 2) || (WM == 2 && WN == 2 && TM == 2 && TN == 2));
+    return BK == 32 && PD == 1 && ((WM == 2 && WN == 4 && TM == 4 && TN == 2) || (WM == 2 && WN == 2 && TM == 2 && TN == 2) || (WM == 2 && WN == 2 && TM == 1 && TN == 1));
 }
 static int g_gemm_dma = 1;  // test hook (test_hooks.h): 0 = always the register-staged kernels
 extern "C" int paella_test_gemm_dma(int on) { g_gemm_dma = on != 0; return PAELLA_OK; }
@@ -752,7 +752,8 @@ static void choose_config(int M, int N, int K, int apro, size_t slab_cap_bytes, 
         cfg = 18;
         G = (T64 >= 2048 || ktiles < 16) ? T64 : 512;  // short K: ranges would be mostly partial tiles
     } else {
-        cfg = 5;
+        // plain operands from 128 rows up: the 1-deep twin whose operands go global -> LDS directly is 2-5 % ahead (profiles/r02_gemm_dma_sweep.txt)
+        cfg = (apro == 0 && M >= 128 && K % 32 == 0) ? 19 : 5;
         const long U = T32 * ktiles;
         G = U / 10;
         if (G < T32) G = T32;
