@@ -41,7 +41,25 @@ struct SkPlan {
     int KT;                // K steps per tile
     unsigned U;            // tiles_m * tiles_n * KT work units
     unsigned q, r;         // U = G*q + r: workgroup g owns [g*q + min(g, r), +q + (g < r)) -- 32-bit arithmetic only on the device
+    int gm;                // tile rasterisation: groups of gm tile rows, m fastest inside a group, then n, then the next group.
+                           // gm >= tiles_m = plain m-fastest order.  The ~32 tiles that run together on an XCD then form a gm x (32 / gm)
+                           // block that shares gm activation panels and 32 / gm weight panels in that XCD's L2 instead of 32 + 1.
 };
+
+// linear tile index -> (tile_m, tile_n)
+__device__ __forceinline__ void sk_tile_coords(const SkPlan& p, int tile, int& tile_m, int& tile_n) {
+    if (p.gm >= p.tiles_m) {
+        tile_m = tile % p.tiles_m;
+        tile_n = tile / p.tiles_m;
+    } else {
+        const int width = p.gm * p.tiles_n;
+        const int grp = tile / width, rem = tile - grp * width;
+        const int first_m = grp * p.gm;
+        const int gsz = min(p.tiles_m - first_m, p.gm);
+        tile_n = rem / gsz;
+        tile_m = first_m + (rem - tile_n * gsz);
+    }
+}
 
 // first unit of workgroup g / the workgroup that owns unit x (inverse of the above)
 __device__ __forceinline__ unsigned sk_start(const SkPlan& p, unsigned g) { return g * p.q + min(g, p.r); }
@@ -163,8 +181,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 &
     int ltap = 0, lc0 = 0;                                  // implicit conv: tap and channel offset of the load cursor's K step
     float ln_mu[APRO == 2 ? LA : 1], ln_rs[APRO == 2 ? LA : 1];
     auto set_tile = [&](int tile) __attribute__((always_inline)) {
-        const int tile_m = tile % p.tiles_m;  // m fastest: consecutive tiles share the weight panel
-        const int tile_n = tile / p.tiles_m;
+        int tile_m, tile_n;
+        sk_tile_coords(p, tile, tile_m, tile_n);
         const int m0 = tile_m * BM, n0 = tile_n * BN;
         size_t a_base;  // bytes from g.A to this tile's descriptor base
         int img0 = 0, smp0 = 0;
@@ -209,7 +227,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 &
         // LayerNorm-on-load: combine the producer's per-16-column (sum, sumsq) partials of this thread's rows; the 8 lanes that
         // share a row (tid & 7) split the blocks and xor-reduce.  fp64 for the final E[x^2] - mean^2.  Computed ONCE: the host
         // only launches this variant with ranges that never change tile_m (tiles_m == 1, or every range inside one tile).
-        const int m0 = (ltile % p.tiles_m) * BM;
+        int ln_tm, ln_tn;
+        sk_tile_coords(p, ltile, ln_tm, ln_tn);
+        const int m0 = ln_tm * BM;
 #pragma unroll
         for (int i = 0; i < LA; ++i) {
             const int gmc = min(m0 + ldrow + i * RP, g.M - 1);
@@ -478,7 +498,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 &
     constexpr unsigned SLOT_BYTES = (unsigned)(NW * FR * 4);  // one slab = one tile of fp32 partial sums
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(slabs, 0, (int)slab_bytes, 0x00020000);
     auto flush = [&](int tile, int k0, int k1, bool first) {
-        const int tile_m = tile % p.tiles_m, tile_n = tile / p.tiles_m;
+        int tile_m, tile_n;
+        sk_tile_coords(p, tile, tile_m, tile_n);
         // launder the lane id: everything the flush derives from it (fragment offsets, output rows / columns, masks) would
         // otherwise be hoisted out of the unit loop and held in ~80 VGPRs across the MFMA stream
         int lane = lane_k;
@@ -688,6 +709,8 @@ template <int WM, int WN, int TM, int TN, int PD, int BK>
 static constexpr bool dma_tile() {
     return BK == 32 && PD == 1 && ((WM == 2 && WN == 4 && TM == 4 && TN == 2) || (WM == 2 && WN == 2 && TM == 2 && TN == 2) || (WM == 2 && WN == 2 && TM == 1 && TN == 1));
 }
+static int g_gemm_raster_gm = 8;  // tile rows per rasterisation group (0 = plain m-fastest); test hook
+extern "C" int paella_test_gemm_raster(int gm) { g_gemm_raster_gm = gm; return PAELLA_OK; }
 static int g_gemm_dma = 1;  // test hook (test_hooks.h): 0 = always the register-staged kernels
 extern "C" int paella_test_gemm_dma(int on) { g_gemm_dma = on != 0; return PAELLA_OK; }
 
@@ -729,7 +752,8 @@ static inline long tiles_of_cfg(int c, int M, int N) {
 // Tile / workgroup-count choice, fitted to tools/gemm_tune.py sweeps on MI355X (profiles/r02_gemm_tile_sweep*.txt,
 // profiles/r02_gemm_midsize_sweep_by_prologue.txt, profiles/r02_gemm_dma_sweep.txt).
 // Returns the tile config and G (number of workgroups = number of contiguous unit ranges).  What the sweeps show:
-//  * >= 1024 tiles of 128x128: one tile per workgroup, 8 waves (cfg 10, direct-to-LDS operands): 126-135 TFLOP/s;
+//  * >= 1024 tiles of 128x128: one tile per workgroup -- 64x64 tiles (cfg 18) for plain operands, the 8-wave 128x128 tile (cfg 10) behind a
+//    prologue; direct-to-LDS operands, tiles rasterised in groups of 8 rows: 130-140 TFLOP/s;
 //  * fewer 128-tiles but >= 5 GFLOP (the batched mid-size shapes, e.g. 4096x1280x1280, 1024x1280x5120, 16384x640x2560): the same
 //    tile as ONE persistent workgroup per CU (G = 256 balanced ranges of (tile, K-step) units) -- best or within 1 % of the best
 //    variant on every shape swept, 2-5 % ahead of 64x64 tiles when K is long; short K (<= 768) with >= 1024 64x64 tiles: one of
@@ -744,8 +768,12 @@ static void choose_config(int M, int N, int K, int apro, size_t slab_cap_bytes, 
     const long T128 = tiles_of_cfg(10, M, N), T64 = tiles_of_cfg(18, M, N), T32 = tiles_of_cfg(5, M, N);
     int cfg;
     long G;
-    if (T128 >= 1024) { cfg = 10; G = T128; }
-    else if (macs >= 2.5e9) {
+    if (T128 >= 1024) {
+        // plain operands: 64x64 tiles, 4 independent workgroups per CU, grouped rasterisation (140 TFLOP/s on 32768x5120x1280);
+        // with a prologue the 8-wave 128x128 tile stages the A operand half as often and ties or wins
+        if (apro == 0) { cfg = 18; G = T64; }
+        else { cfg = 10; G = T128; }
+    } else if (macs >= 2.5e9) {
         if (K <= 768 && T64 >= 1024) { cfg = 18; G = T64; }
         else { cfg = 10; G = 256; }
     } else if (macs >= 1.2e9 || T64 >= 1024) {
@@ -907,6 +935,8 @@ static int launch_gemm_cfg_impl(const GemmArgs& g, int cfg, int splitk, void* ws
     }
     p.q = p.U / G;
     p.r = p.U % G;
+    // grouped rasterisation for launches with many tile rows and columns (test hook: paella_test_gemm_raster)
+    p.gm = (g_gemm_raster_gm > 0 && p.tiles_m > g_gemm_raster_gm && p.tiles_n >= 4) ? g_gemm_raster_gm : p.tiles_m;
     unsigned* tickets = have_ws ? reinterpret_cast<unsigned*>(ws) : nullptr;
     float* slabs = have_ws ? reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + kGemmTicketBytes) : nullptr;
 #define GEMM_CASE(id, WMv, WNv, TMv, TNv, PDv) \
@@ -979,6 +1009,7 @@ int launch_gemm_tail(const GemmArgs& g, hipStream_t st) {
     p.U = (unsigned)(T * p.KT);
     p.q = (unsigned)p.KT;  // one whole tile per workgroup
     p.r = 0;
+    p.gm = p.tiles_m;
     if (cfg == 9) hipLaunchKernelGGL((gemm_nt_kernel<4, 2, 2, 4, 1, 0, true>), dim3((unsigned)T), dim3(512), 0, st, g, p, (float*)nullptr, (unsigned*)nullptr, 0u);
     else hipLaunchKernelGGL((gemm_nt_kernel<2, 2, 2, 2, 2, 0, true>), dim3((unsigned)T), dim3(256), 0, st, g, p, (float*)nullptr, (unsigned*)nullptr, 0u);
     LAUNCH_CHECK_RET();

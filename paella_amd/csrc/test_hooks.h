@@ -19,6 +19,8 @@ int paella_test_gemm_prologue(const float* A, const float* W, float* C, int M, i
                               int rows_per_sample, const float* ln_stats, int tile_cfg, int splitk, void* ws, size_t ws_bytes, void* stream);
 /* 0 = never use the direct-to-LDS (DMA) twins of the large GEMM tiles (A/B and parity checks); 1 = default */
 int paella_test_gemm_dma(int on);
+/* tile rows per rasterisation group of the GEMM (default 8); 0 = plain m-fastest tile order (A/B) */
+int paella_test_gemm_raster(int gm);
 #ifdef __cplusplus
 }
 #endif

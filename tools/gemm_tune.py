@@ -52,9 +52,12 @@ def main():
     ap.add_argument("--big-only", action="store_true", help="only the large-tile candidates without split-K")
     ap.add_argument("--only", default=None, help="substring filter on the shape name (comma-separated alternatives)")
     ap.add_argument("--apro", type=int, default=0, choices=[0, 1, 2], help="A-operand prologue: 0 none, 1 GRN scale/shift (rows per sample = 64), 2 LayerNorm from row statistics")
+    ap.add_argument("--raster", type=int, default=None, help="tile rows per rasterisation group (test hook; 0 = plain m-fastest order)")
     ap.add_argument("--cfgs", default=None, help="comma-separated tile configs to sweep (default: all that fit)")
     a = ap.parse_args()
     lib = _lib.load()
+    if a.raster is not None:
+        lib.paella_test_gemm_raster(a.raster)
     st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     ws = _lib.new_workspace(256 << 20, "cuda")
     results = {}
