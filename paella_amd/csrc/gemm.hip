@@ -46,9 +46,11 @@ struct SkPlan {
                            // block that shares gm activation panels and 32 / gm weight panels in that XCD's L2 instead of 32 + 1.
 };
 
-// linear tile index -> (tile_m, tile_n)
+// linear tile index -> (tile_m, tile_n); GROUPED is a compile-time property of the tile (rows >= 64): the skinny batch-1 kernels keep the
+// two-instruction plain form (the runtime-selected form cost them 2 % per image)
+template <bool GROUPED>
 __device__ __forceinline__ void sk_tile_coords(const SkPlan& p, int tile, int& tile_m, int& tile_n) {
-    if (p.gm >= p.tiles_m) {
+    if (!GROUPED || p.gm >= p.tiles_m) {
         tile_m = tile % p.tiles_m;
         tile_n = tile / p.tiles_m;
     } else {
@@ -182,7 +184,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 &
     float ln_mu[APRO == 2 ? LA : 1], ln_rs[APRO == 2 ? LA : 1];
     auto set_tile = [&](int tile) __attribute__((always_inline)) {
         int tile_m, tile_n;
-        sk_tile_coords(p, tile, tile_m, tile_n);
+        sk_tile_coords<(BM >= 64)>(p, tile, tile_m, tile_n);
         const int m0 = tile_m * BM, n0 = tile_n * BN;
         size_t a_base;  // bytes from g.A to this tile's descriptor base
         int img0 = 0, smp0 = 0;
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 &
         // share a row (tid & 7) split the blocks and xor-reduce.  fp64 for the final E[x^2] - mean^2.  Computed ONCE: the host
         // only launches this variant with ranges that never change tile_m (tiles_m == 1, or every range inside one tile).
         int ln_tm, ln_tn;
-        sk_tile_coords(p, ltile, ln_tm, ln_tn);
+        sk_tile_coords<(BM >= 64)>(p, ltile, ln_tm, ln_tn);
         const int m0 = ln_tm * BM;
 #pragma unroll
         for (int i = 0; i < LA; ++i) {
@@ -499,7 +501,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 &
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(slabs, 0, (int)slab_bytes, 0x00020000);
     auto flush = [&](int tile, int k0, int k1, bool first) {
         int tile_m, tile_n;
-        sk_tile_coords(p, tile, tile_m, tile_n);
+        sk_tile_coords<(BM >= 64)>(p, tile, tile_m, tile_n);
         // launder the lane id: everything the flush derives from it (fragment offsets, output rows / columns, masks) would
         // otherwise be hoisted out of the unit loop and held in ~80 VGPRs across the MFMA stream
         int lane = lane_k;
@@ -936,7 +938,9 @@ static int launch_gemm_cfg_impl(const GemmArgs& g, int cfg, int splitk, void* ws
     p.q = p.U / G;
     p.r = p.U % G;
     // grouped rasterisation for launches with many tile rows and columns (test hook: paella_test_gemm_raster)
-    p.gm = (g_gemm_raster_gm > 0 && p.tiles_m > g_gemm_raster_gm && p.tiles_n >= 4) ? g_gemm_raster_gm : p.tiles_m;
+    // (32-row tiles and skinny problems keep the plain order: their traffic is the weight panel, which m-fastest tiles share best --
+    // measured +2 % per image at batch 1 with groups there)
+    p.gm = (g_gemm_raster_gm > 0 && BM >= 64 && p.tiles_m >= 4 * g_gemm_raster_gm && p.tiles_n >= 4) ? g_gemm_raster_gm : p.tiles_m;
     unsigned* tickets = have_ws ? reinterpret_cast<unsigned*>(ws) : nullptr;
     float* slabs = have_ws ? reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + kGemmTicketBytes) : nullptr;
 #define GEMM_CASE(id, WMv, WNv, TMv, TNv, PDv) \
