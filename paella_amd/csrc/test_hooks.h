@@ -1,5 +1,6 @@
 /* Test / tooling hooks exported by libpaella_hip.so but NOT part of the public C ABI (include/paella_hip.h).
- * Bound by paella_amd/_lib.py (TEST_HOOKS) for tests/test_gpu_fastmode.py and tools/launch_floor.py only. */
+ * Bound by paella_amd/_lib.py (TEST_HOOKS) for tests/ and tools/ only.  The switches are process-wide plain variables read at launch time:
+ * set them from one host thread, while no other thread is enqueueing work (none of them is reachable from the product path). */
 #ifndef PAELLA_TEST_HOOKS_H
 #define PAELLA_TEST_HOOKS_H
 #include <stddef.h>

@@ -99,3 +99,32 @@ def test_classic_cases_are_special_cases():
     for g in range(G):
         (tile, k0, k1, first), = writer_segments(g, U, G, KT)
         assert tile == g // S and k0 == (g % S) * (KT // S) and k1 == k0 + KT // S and first
+
+
+def tile_coords(tile, tiles_m, tiles_n, gm):
+    """sk_tile_coords of gemm.hip: groups of gm tile rows, m fastest inside a group, then n, then the next group (gm >= tiles_m:
+    plain m-fastest order)."""
+    if gm >= tiles_m:
+        return tile % tiles_m, tile // tiles_m
+    width = gm * tiles_n
+    grp, rem = divmod(tile, width)
+    first_m = grp * gm
+    gsz = min(tiles_m - first_m, gm)
+    tile_n, dm = divmod(rem, gsz)
+    return first_m + dm, tile_n
+
+
+@pytest.mark.parametrize("tiles_m,tiles_n,gm", [(32, 4, 8), (33, 5, 8), (39, 7, 8), (40, 4, 16), (64, 40, 8), (7, 9, 8), (100, 3, 8), (32, 6, 4), (35, 4, 32)])
+def test_grouped_rasterisation_is_a_bijection_with_block_locality(tiles_m, tiles_n, gm):
+    """Every (tile_m, tile_n) is produced exactly once (ragged last group included), and any window of gm * 4 consecutive tiles inside
+    a full group touches at most gm tile rows and 5 tile columns -- the L2-sharing property the order exists for."""
+    T = tiles_m * tiles_n
+    coords = [tile_coords(t, tiles_m, tiles_n, gm) for t in range(T)]
+    assert sorted(coords) == sorted(itertools.product(range(tiles_m), range(tiles_n)))
+    if gm < tiles_m:
+        full_groups = tiles_m // gm
+        for t0 in range(0, full_groups * gm * tiles_n - gm * 4, 7):
+            win = coords[t0:t0 + gm * 4]
+            if win[0][0] // gm != win[-1][0] // gm:
+                continue  # window straddles two row groups
+            assert len({m for m, _ in win}) <= gm and len({n for _, n in win}) <= 5
