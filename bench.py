@@ -344,7 +344,7 @@ def main():
                 r = gemm_roofline(lib, lambda: efn(c0e, u0e), device, a.model, eb, eg, es, a.gemm, True)
                 throughput.append({"workload": "%s: batch %d per GPU, %dx%d tokens, %d steps, CFG 8.0, + VQGAN f8 decode"
                                                % (WORKLOAD_TAG.get((a.model, eb, eg, es), "configs[1] model at a throughput batch"), eb, eg, eg, es),
-                                   "batch": eb, "n_gpus": world, "global_batch": tot_e, "grid": eg, "sample_steps": es, "steps": k, "warmup": w,
+                                   "batch": eb, "n_gpus": world, "images_per_step": tot_e, "grid": eg, "sample_steps": es, "steps": k, "warmup": w,
                                    "images_per_sec": round(tot_e * k / dte, 3), "ms_per_image": round(dte / (tot_e * k) * 1e3, 3),
                                    "roofline": {kk: r[kk] for kk in ("bound", "achieved", "peak", "unit", "frac", "executed_tflops", "executed_frac",
                                                                       "launches_per_step", "avg_launch_us", "gemm_ms_per_step", "traffic", "traffic_source",
@@ -373,7 +373,7 @@ def main():
             "config": {"workload": WORKLOAD_TAG.get((a.model, a.batch, a.grid, a.sample_steps), "custom") + ": Paella 573M-class (stand-in blocks=[4,8,4], %.1fM params), %dx%d tokens = %d px, "
                                    "%d steps, CFG 8.0, CLIP-H-text only (S=4), batch %d per GPU, + VQGAN f8 decode"
                                    % (n_params / 1e6, a.grid, a.grid, a.grid * 8, a.sample_steps, a.batch),
-                       "model": a.model, "batch_per_gpu": a.batch, "global_batch": total, "grid": a.grid, "sample_steps": a.sample_steps,
+                       "denoiser": a.model, "images_per_gpu_per_step": a.batch, "images_per_step": total, "token_grid": a.grid, "sample_steps": a.sample_steps,
                        "noise": a.noise, "submission": "hip-graph replay" if use_graph else "eager launches",
                        "parallelism": "batch-shard x%d, one conditioning broadcast per step" % world,
                        "world_size_observed": (dist.get_world_size() if distributed else 1),
