@@ -95,3 +95,20 @@ def test_synth_weights_are_deterministic():
     b = synth.synth_state_dict(m.state_dict(), seed=0, n_blocks=4)
     assert all(torch.equal(a[k], b[k]) for k in a)
     assert synth.checksum(a) == synth.checksum(b)
+
+
+def test_bench_traffic_files_are_stamped_and_stale_ones_refused(monkeypatch):
+    """bench.py's `roofline.traffic` comes from committed rocprofv3 PMC passes; each file carries the hash of the kernel sources it was
+    measured on.  A file measured on other sources must be refused (traffic null + the reason), never silently reused."""
+    import bench
+    for wl in [(1, 32, 8), (32, 32, 8), (64, 64, 12)]:
+        val, note = bench.load_traffic("570m", *wl)
+        if val is None:  # kernels edited since the last collection (tools/collect_profiles.sh): reported, not hidden
+            assert "no PMC traffic file for the current kernel sources" in note
+        else:
+            assert val > 0 and bench.source_stamp() in note
+    monkeypatch.setattr(bench, "source_stamp", lambda: "0" * 16)
+    val, note = bench.load_traffic("570m", 1, 32, 8)
+    assert val is None and "stale" in note and "refused" in note
+    val, note = bench.load_traffic("570m", 7, 32, 8)  # a workload nobody profiled
+    assert val is None
