@@ -117,11 +117,20 @@ def save(name, **arrays):
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 
 
-def make_train_golden(ref):
+TRAIN_GOLDENS = {  # fixture name -> (config, parameters whose gradient is stored in full)
+    "train_tiny_step": ("UNET_TINY", ("in_mapper.0.weight", "byt5_mapper.weight", "down_blocks.1.3.attention.attn.in_proj_weight", "down_blocks.1.1.channelwise.2.gamma",
+                                      "down_blocks.0.1.mapper.weight", "up_blocks.0.0.depthwise.weight", "clf.1.weight", "out_mapper.1.weight", "up_blocks.1.6.1.weight")),
+    # FeedForwardBlock ('F'), cross-attention only (self_attn=False), patch_size 1, two levels, level_config ['CFT', 'TAC']
+    "train_variant_step": ("UNET_VARIANT", None),
+}
+
+
+def make_train_golden(ref, name="train_tiny_step"):
     """One training step of the REFERENCE (src_distributed/train.py:98-114 call sequence: add_noise -> get_loss_weight -> model(...)
-    in train mode with dropout 0.1 -> label-smoothed CE weighted by loss_weight -> backward) on the tiny config; stores the loss,
-    the logits and the gradient of every parameter as (norm, sum) plus a few small tensors in full."""
-    cfg = G.UNET_TINY
+    in train mode with dropout 0.1 -> label-smoothed CE weighted by loss_weight -> backward); stores the loss, the logits and the
+    gradient of every parameter as (norm, sum) plus a few small tensors in full."""
+    cfg_name, full_keys = TRAIN_GOLDENS[name]
+    cfg = getattr(G, cfg_name)
     # src_distributed/modules.py carries get_loss_weight; same network as src/modules.py
     mod = load_module(os.path.join(REF, "src_distributed", "modules.py"), "ref_dist_modules")
     torch.manual_seed(0)
@@ -134,9 +143,9 @@ def make_train_golden(ref):
         m.train()
         for mm in m.modules():  # "nodrop": dropout off but still train mode (pure gradient check); "drop": the reference's 0.1
             if isinstance(mm, nn.Dropout):
-                mm.p = 0.0 if p_drop_seed is None else cfg["dropout"]
+                mm.p = 0.0 if p_drop_seed is None else 0.1
             if isinstance(mm, nn.MultiheadAttention):
-                mm.dropout = 0.0 if p_drop_seed is None else cfg["dropout"]
+                mm.dropout = 0.0 if p_drop_seed is None else 0.1
         m.zero_grad(set_to_none=True)
         noised, mk = m.add_noise(latents, t, mask=mask, random_x=random_x)
         lw = m.get_loss_weight(t, mk)
@@ -151,18 +160,27 @@ def make_train_golden(ref):
         out[tag + "_pred_sub"] = pred.detach()[:, ::4, ::2, ::2].contiguous()
         out[tag + "_grad_norms"] = torch.stack([p.grad.norm() for _, p in m.named_parameters()])
         out[tag + "_grad_sums"] = torch.stack([p.grad.double().sum().float() for _, p in m.named_parameters()])
-        for k in ("in_mapper.0.weight", "byt5_mapper.weight", "down_blocks.1.3.attention.attn.in_proj_weight", "down_blocks.1.1.channelwise.2.gamma",
-                  "down_blocks.0.1.mapper.weight", "up_blocks.0.0.depthwise.weight", "clf.1.weight", "out_mapper.1.weight", "up_blocks.1.6.1.weight"):
+        keys = full_keys
+        if keys is None:  # the first parameter of every kind, small tensors only
+            keys, seen = [], set()
+            for k, p in m.named_parameters():
+                kind = ".".join(s for s in k.split(".") if not s.isdigit())
+                if kind not in seen and p.numel() <= 6000 and len(keys) < 16:
+                    seen.add(kind)
+                    keys.append(k)
+        for k in keys:
             out[tag + "_grad:" + k] = dict(m.named_parameters())[k].grad.detach().clone()
-    save("train_tiny_step", names=np.array(names), checksum=np.array(synth.checksum(sd)), **out)
+    save(name, names=np.array(names), checksum=np.array(synth.checksum(sd)), **out)
 
 
 def main():
     ref = import_reference()
     if "--only-train" in sys.argv:
-        make_train_golden(ref)
+        for name in TRAIN_GOLDENS:
+            make_train_golden(ref, name)
         return
-    make_train_golden(ref)
+    for name in TRAIN_GOLDENS:
+        make_train_golden(ref, name)
     with torch.no_grad():
         # ---- 1. forward, tiny ----
         cfg = G.UNET_TINY

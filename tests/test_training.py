@@ -20,8 +20,15 @@ def model(golden):
     return m
 
 
-def _step(m, p_drop, seed):
-    cfg = G.UNET_TINY
+@pytest.fixture(scope="module")
+def variant_model(golden):
+    """FeedForwardBlock ('F'), cross-attention only (self_attn=False), patch_size 1, two levels (level_config ['CFT', 'TAC'])."""
+    m = paella_amd.Paella(**G.UNET_VARIANT)
+    weights_for(m, sum(G.UNET_VARIANT["blocks"]), golden("unet_variant_forward"))
+    return m
+
+
+def _step(m, p_drop, seed, cfg=G.UNET_TINY):
     latents, t, mask, random_x, c = G.train_step_inputs(cfg)
     m.train()
     m.dropout = p_drop
@@ -39,9 +46,11 @@ def _step(m, p_drop, seed):
 
 
 @pytest.mark.parametrize("tag,p_drop,seed", [("nodrop", 0.0, None), ("drop", 0.1, 1234)])
-def test_training_step_matches_reference(golden, model, tag, p_drop, seed):
-    g = golden("train_tiny_step")
-    pred, loss = _step(model, p_drop, seed)
+@pytest.mark.parametrize("which", ["tiny", "variant"])
+def test_training_step_matches_reference(golden, model, variant_model, which, tag, p_drop, seed):
+    g = golden("train_%s_step" % which)
+    model, cfg = (model, G.UNET_TINY) if which == "tiny" else (variant_model, G.UNET_VARIANT)
+    pred, loss = _step(model, p_drop, seed, cfg)
     np.testing.assert_allclose(float(loss), float(g[tag + "_loss"]), rtol=1e-5)
     np.testing.assert_allclose(pred[:, ::4, ::2, ::2].numpy(), g[tag + "_pred_sub"], atol=2e-5, rtol=1e-5)
     params = dict(model.named_parameters())
