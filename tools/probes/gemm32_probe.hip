@@ -18,8 +18,7 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 256, BN = 128, BK = 32, NT = 512;
-constexpr int TILE_FLOATS = (BM + BN) * BK;  // 48 KiB per stage
+constexpr int BK = 32, NT = 512;
 
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, float* lds_wave_base, unsigned voffset, int soffset) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -27,11 +26,15 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, float* lds_wa
 #endif
 }
 
+template <int BM, int BN, int WM, int WN>  // workgroup tile, waves along M / N (WM * WN == 8); wave tile = (BM / WM) x (BN / WN) in 32x32 MFMA tiles
 __global__ __launch_bounds__(NT) void gemm32_kernel(const float* __restrict__ A, const float* __restrict__ W, float* __restrict__ C, int M, int N, int K, int gm) {
+    constexpr int TILE_FLOATS = (BM + BN) * BK;
+    constexpr int TI = BM / WM / 32, TJ = BN / WN / 32, PA = BM / 64, PB = BN / 64;
+    static_assert(WM * WN == 8, "8 waves");
     __shared__ __attribute__((aligned(16))) float smem[2 * TILE_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int r32 = lane & 31, h = lane >> 5;
     const int tiles_m = M / BM, tiles_n = N / BN;
     // XCD-aware order (workgroup b runs on XCD b % 8) + grouped rasterisation, as in the product kernel
@@ -51,17 +54,17 @@ __global__ __launch_bounds__(NT) void gemm32_kernel(const float* __restrict__ A,
     const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A + (size_t)m0 * K), 0, BM * K * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W + (size_t)n0 * K), 0, BN * K * 4, 0x00020000);
     const int ldrow = tid >> 3, ldc = tid & 7;  // 64 rows per pass, 8 chunks of 16 bytes per row
-    unsigned aoff[4], boff[2];
+    unsigned aoff[PA], boff[PB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) aoff[i] = ((unsigned)(ldrow + 64 * i) * (unsigned)K + (unsigned)((ldc ^ (ldrow & 7)) * 4)) * 4u;
+    for (int i = 0; i < PA; ++i) aoff[i] = ((unsigned)(ldrow + 64 * i) * (unsigned)K + (unsigned)((ldc ^ (ldrow & 7)) * 4)) * 4u;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) boff[i] = ((unsigned)(ldrow + 64 * i) * (unsigned)K + (unsigned)((ldc ^ (ldrow & 7)) * 4)) * 4u;
+    for (int i = 0; i < PB; ++i) boff[i] = ((unsigned)(ldrow + 64 * i) * (unsigned)K + (unsigned)((ldc ^ (ldrow & 7)) * 4)) * 4u;
 
-    f32x16 acc[2][2];
+    f32x16 acc[TI][TJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TJ; ++j)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
 
@@ -70,36 +73,36 @@ __global__ __launch_bounds__(NT) void gemm32_kernel(const float* __restrict__ A,
         float* dB = smem + stage * TILE_FLOATS + BM * BK + (wave * 8) * BK;
         const int kofs = kt * (BK * 4);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dma16(rsrcA, dA + 64 * i * BK, aoff[i], kofs);
+        for (int i = 0; i < PA; ++i) dma16(rsrcA, dA + 64 * i * BK, aoff[i], kofs);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) dma16(rsrcW, dB + 64 * i * BK, boff[i], kofs);
+        for (int i = 0; i < PB; ++i) dma16(rsrcW, dB + 64 * i * BK, boff[i], kofs);
     };
-    auto read_block = [&](int stage, int b, f32x4 (&af)[2], f32x4 (&bf)[2]) __attribute__((always_inline)) {
+    auto read_block = [&](int stage, int b, f32x4 (&af)[TI], f32x4 (&bf)[TJ]) __attribute__((always_inline)) {
         const float* As = smem + stage * TILE_FLOATS;
         const float* Bs = As + BM * BK;
         const int c = 2 * b + h;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = wm * 64 + i * 32 + r32;
+        for (int i = 0; i < TI; ++i) {
+            const int row = wm * (BM / WM) + i * 32 + r32;
             af[i] = *reinterpret_cast<const f32x4*>(As + row * BK + ((c ^ (row & 7)) << 2));
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int row = wn * 64 + j * 32 + r32;
+        for (int j = 0; j < TJ; ++j) {
+            const int row = wn * (BN / WN) + j * 32 + r32;
             bf[j] = *reinterpret_cast<const f32x4*>(Bs + row * BK + ((c ^ (row & 7)) << 2));
         }
     };
-    auto mfma_block = [&](const f32x4 (&af)[2], const f32x4 (&bf)[2]) __attribute__((always_inline)) {
+    auto mfma_block = [&](const f32x4 (&af)[TI], const f32x4 (&bf)[TJ]) __attribute__((always_inline)) {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TI; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j][e], af[i][e], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j][e], af[i][e], acc[i][j], 0, 0, 0);
     };
 
     const int KT = K / BK;
-    f32x4 a0[2], b0[2], a1[2], b1[2];
+    f32x4 a0[TI], b0[TJ], a1[TI], b1[TJ];
     issue(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -135,13 +138,13 @@ __global__ __launch_bounds__(NT) void gemm32_kernel(const float* __restrict__ A,
 
     // D = W_tile . A_tile^T: lane holds out[m = ..+r32][n = .. + 8g + 4h + 0..3] for g = 0..3
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = m0 + wm * 64 + i * 32 + r32;
+    for (int i = 0; i < TI; ++i) {
+        const int m = m0 + wm * (BM / WM) + i * 32 + r32;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TJ; ++j)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int n = n0 + wn * 64 + j * 32 + 8 * g + 4 * h;
+                const int n = n0 + wn * (BN / WN) + j * 32 + 8 * g + 4 * h;
                 const f32x4 v = f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
                 *reinterpret_cast<f32x4*>(C + (size_t)m * N + n) = v;
             }
@@ -182,7 +185,7 @@ int main(int argc, char** argv) {
         hipMemcpy(A, hA.data(), hA.size() * 4, hipMemcpyHostToDevice);
         hipMemcpy(W, hW.data(), hW.size() * 4, hipMemcpyHostToDevice);
         hipMemset(C, 0xff, hC.size() * 4);
-        hipLaunchKernelGGL(gemm32_kernel, dim3((M / BM) * (N / BN)), dim3(NT), 0, 0, A, W, C, M, N, K, 8);
+        hipLaunchKernelGGL((gemm32_kernel<256, 128, 4, 2>), dim3((M / 256) * (N / 128)), dim3(NT), 0, 0, A, W, C, M, N, K, 8);
         hipLaunchKernelGGL(naive_kernel, dim3((N + 255) / 256, M), dim3(256), 0, 0, A, W, R, M, N, K);
         hipDeviceSynchronize();
         hipMemcpy(hC.data(), C, hC.size() * 4, hipMemcpyDeviceToHost);
@@ -200,20 +203,29 @@ int main(int argc, char** argv) {
         hipMalloc(&A, (size_t)M * K * 4); hipMalloc(&C, (size_t)M * N * 4);
         hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, A, (size_t)M * K, 7u);
         { unsigned sd = 11u; for (auto& w : W) { hipMalloc(&w, (size_t)N * K * 4); hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, w, (size_t)N * K, sd++); } }
-        const int tiles = (M / BM) * (N / BN);
+        auto run = [&](int variant, int gm, int i) {
+            switch (variant) {
+                case 0: hipLaunchKernelGGL((gemm32_kernel<256, 128, 4, 2>), dim3((M / 256) * (N / 128)), dim3(NT), 0, 0, A, W[i], C, M, N, K, gm); break;
+                case 1: hipLaunchKernelGGL((gemm32_kernel<256, 256, 4, 2>), dim3((M / 256) * (N / 256)), dim3(NT), 0, 0, A, W[i], C, M, N, K, gm); break;
+                case 2: hipLaunchKernelGGL((gemm32_kernel<256, 256, 2, 4>), dim3((M / 256) * (N / 256)), dim3(NT), 0, 0, A, W[i], C, M, N, K, gm); break;
+                default: hipLaunchKernelGGL((gemm32_kernel<128, 256, 2, 4>), dim3((M / 128) * (N / 256)), dim3(NT), 0, 0, A, W[i], C, M, N, K, gm); break;
+            }
+        };
+        const char* names[] = {"256x128 (4x2 waves)", "256x256 (4x2 waves)", "256x256 (2x4 waves)", "128x256 (2x4 waves)"};
+        for (int variant = 0; variant < 4; ++variant)
         for (int gm : {8, 1 << 30}) {
             hipEvent_t e0, e1;
             hipEventCreate(&e0); hipEventCreate(&e1);
-            for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(gemm32_kernel, dim3(tiles), dim3(NT), 0, 0, A, W[i], C, M, N, K, gm);
+            for (int i = 0; i < 3; ++i) run(variant, gm, i);
             const int reps = M >= 32768 ? 9 : 30;
             hipEventRecord(e0);
-            for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(gemm32_kernel, dim3(tiles), dim3(NT), 0, 0, A, W[i % 3], C, M, N, K, gm);
+            for (int i = 0; i < reps; ++i) run(variant, gm, i % 3);
             hipEventRecord(e1);
             hipEventSynchronize(e1);
             float ms = 0;
             hipEventElapsedTime(&ms, e0, e1);
             const double us = ms * 1e3 / reps;
-            printf("%6d x %5d x %5d  256x128 tile, 32x32x2 MFMA, DMA, %s: %8.1f us  %6.1f TFLOP/s\n", M, N, K, gm == 8 ? "grouped raster 8" : "m-fastest order  ", us,
+            printf("%6d x %5d x %5d  %s, 32x32x2 MFMA, DMA, %s: %8.1f us  %6.1f TFLOP/s\n", M, N, K, names[variant], gm == 8 ? "grouped raster 8" : "m-fastest order  ", us,
                    2.0 * M * N * K / us / 1e6);
         }
         hipFree(A); hipFree(C);
