@@ -51,7 +51,8 @@ WORKLOAD_TAG = {("570m", 1, 32, 8): "BASELINE configs[1]", ("570m", 64, 64, 12):
 # SURVEY.md section 8(d)/8(a), per image: 2 * steps * F_fwd(model, grid, S=4) + VQGAN f8 decode, in GFLOP (the GEMM-shaped work)
 ALGO_GFLOP_PER_IMAGE = {("570m", 32, 8): 2 * 8 * 66.27 + 38.8, ("570m", 64, 12): 2 * 12 * 266.5 + 155.0}
 # the kernel sources the roofline's PMC traffic figure belongs to (profiles/*_pmc_traffic.json is stamped with their hash)
-TRAFFIC_SOURCES = ["paella_amd/csrc/gemm.hip", "paella_amd/csrc/gemm_device.h", "paella_amd/csrc/model.hip", "paella_amd/csrc/common.h"]
+TRAFFIC_SOURCES = ["paella_amd/csrc/gemm.hip", "paella_amd/csrc/gemm_device.h", "paella_amd/csrc/philox.h", "paella_amd/csrc/tail.hip", "paella_amd/csrc/model.hip",
+                   "paella_amd/csrc/common.h"]
 
 
 def parse():
@@ -268,16 +269,20 @@ def main():
         if use_graph:  # capture sample() + decode once for these shapes; every step replays it with fresh conditioning / seed
             sampler = paella_amd.GraphSampler(model, mk_cond(batch, 2), mk_cond(batch, 3), (batch, grid, grid), vqgan=vq, **kw)
 
+        # shard-exact noise: every rank keys its Philox draws with the SAME per-step seed and its GLOBAL row offset, so the N-GPU job
+        # produces exactly the images of the unsharded batch (tests/test_gpu_sample.py::test_graph_sampler_shard_equals_unsharded)
+        shard = (rank * batch, world * batch) if a.noise == "philox" else None
+
         def eager(c, u):
             counter[0] += 1
-            toks = paella_amd.sample(model, c, (batch, grid, grid), unconditional_inputs=u, noise=a.noise, seed=seed_base + 1000 * counter[0] + rank, **kw)
+            toks = paella_amd.sample(model, c, (batch, grid, grid), unconditional_inputs=u, noise=a.noise, seed=seed_base + 1000 * counter[0], shard=shard, **kw)
             return vq.decode_indices(toks)
 
         def step(c, u):
             if sampler is None:
                 return eager(c, u)
             counter[0] += 1
-            return sampler(c, u, seed=seed_base + 1000 * counter[0] + rank)[1]
+            return sampler(c, u, seed=seed_base + 1000 * counter[0], shard=shard)[1]
         return step, eager
 
     step_fn, eager_fn = make_runner(a.batch, a.grid, a.sample_steps, 0)
@@ -375,7 +380,7 @@ def main():
                                    % (n_params / 1e6, a.grid, a.grid, a.grid * 8, a.sample_steps, a.batch),
                        "denoiser": a.model, "images_per_gpu_per_step": a.batch, "images_per_step": total, "token_grid": a.grid, "sample_steps": a.sample_steps,
                        "noise": a.noise, "submission": "hip-graph replay" if use_graph else "eager launches",
-                       "parallelism": "batch-shard x%d, one conditioning broadcast per step" % world,
+                       "parallelism": "batch-shard x%d, one conditioning broadcast per step, shard-exact Philox noise (global-row keyed)" % world,
                        "world_size_observed": (dist.get_world_size() if distributed else 1),
                        "collective_backend": (dist.get_backend() + " (RCCL)" if distributed else None)},
             "roofline": roof, "cpu_baseline": cpu, "throughput": throughput,

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PAELLA_ABI_VERSION 2
+#define PAELLA_ABI_VERSION 3
 
 #define PAELLA_OK 0
 #define PAELLA_ERR_ARG -1       /* invalid argument / unsupported shape */
@@ -140,8 +140,8 @@ int paella_unet_forward_shared(paella_unet* m, const int64_t* tokens, const floa
 int paella_unet_forward_sample(paella_unet* m, const int64_t* tokens, const float* r, const void* cond, int B, int n_unique,
                                float mix_c, float mix_u, int H, int W, int S, const float* attn_weights, int n_attn_weights,
                                float temperature, int mode, uint64_t seed, const uint64_t* seed_ptr, uint64_t offset,
-                               int64_t row_offset, const int64_t* init_noise, float t_next, int64_t* tokens_out, void* ws,
-                               size_t ws_bytes, void* stream);
+                               int64_t row_offset, const int64_t* row_offset_ptr, const int64_t* init_noise, float t_next,
+                               int64_t* tokens_out, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Sampling tail and add_noise (reference src/utils.py:45-54; src/modules.py:277-283)
@@ -160,11 +160,20 @@ int paella_sample_tail(const float* logits_c, const float* logits_u, int64_t row
 /* Same, with (a) an optional DEVICE-resident seed word added to `seed` (seed_ptr may be NULL): a HIP graph that captured
  * the sampling loop can then be replayed with fresh noise by rewriting that one word; (b) row_offset: the Philox counters
  * are keyed by (row + row_offset), so a batch shard that owns global rows [lo, hi) passes lo * H * W and draws exactly the
- * noise the unsharded call draws for those rows (sharded == unsharded). */
+ * noise the unsharded call draws for those rows (sharded == unsharded); (c) row_offset_ptr (may be NULL): a
+ * DEVICE-resident word added to row_offset, so ONE captured graph serves any batch shard by rewriting that word. */
 int paella_sample_tail_ex(const float* logits_c, const float* logits_u, int64_t rows, int L, float cfg,
                           float one_minus_cfg, float temperature, int mode, const float* noise_q, uint64_t seed,
-                          const uint64_t* seed_ptr, uint64_t offset, int64_t row_offset, const int64_t* init_noise,
-                          const float* mask_u, float t_next, int64_t* tokens_out, int64_t* sampled_out, void* stream);
+                          const uint64_t* seed_ptr, uint64_t offset, int64_t row_offset, const int64_t* row_offset_ptr,
+                          const int64_t* init_noise, const float* mask_u, float t_next, int64_t* tokens_out,
+                          int64_t* sampled_out, void* stream);
+
+/* Start tokens of the counter-based noise mode (the reference draws torch.randint(0, num_labels, (B,H,W)) from the global
+ * generator, src/utils.py:37 -- a stream that cannot be sharded): tokens_out[i] = Philox(seed + *seed_ptr, i + row_offset +
+ * *row_offset_ptr) mod num_labels for i in [0, n).  A shard that owns global rows [lo, hi) passes row_offset = lo * H * W and
+ * n = (hi - lo) * H * W and obtains exactly its slice of the unsharded draw.  Either pointer may be NULL. */
+int paella_start_tokens(uint64_t seed, const uint64_t* seed_ptr, int64_t row_offset, const int64_t* row_offset_ptr,
+                        int num_labels, int64_t n, int64_t* tokens_out, void* stream);
 
 /* x, random_x, mask int64 [B, per_sample]; t fp32 [B].  mask_in NULL -> mask = (u <= t[b]) with u = rand_u
  * (caller noise, [B, per_sample]) or Philox; random_x NULL -> Philox randint(0, num_labels). */
@@ -226,12 +235,6 @@ int paella_op_attention(const float* q, const float* k_self, const float* v_self
                         const float* v_cond, float* out, int B, int nhead, int D, int Lq, int Lself, int Lcond,
                         const float* key_weights, int n_kw, void* stream);
 
-/* ------------------------------------------------------------------------------------------------
- * Measurement hook (bench.py roofline line): when enabled, every dense-contraction launch is bracketed by HIP
- * events on its stream; collect() returns the summed duration, algorithmic FLOPs and bytes since enable(1).
- * ---------------------------------------------------------------------------------------------- */
-int paella_prof_enable(int on);
-int paella_prof_collect(double* total_ms, double* total_flops, double* total_bytes, int64_t* launches);
 #ifdef __cplusplus
 }
 #endif

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libpaella_hip.so")
 
 MAX_LEVELS = 8
 MAX_BLOCK_TYPES = 8
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class UnetConfig(Structure):
@@ -57,12 +57,13 @@ SIGNATURES = {
     "paella_unet_forward_shared": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_int, c_int, c_int,
                                            c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "paella_unet_forward_sample": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_int, c_int, c_int,
-                                           c_void_p, c_int, c_float, c_int, c_uint64, c_void_p, c_uint64, c_int64, c_void_p, c_float, c_void_p,
+                                           c_void_p, c_int, c_float, c_int, c_uint64, c_void_p, c_uint64, c_int64, c_void_p, c_void_p, c_float, c_void_p,
                                            c_void_p, c_size_t, c_void_p]),
     "paella_sample_tail": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, c_float, c_float, c_int, c_void_p,
                                    c_uint64, c_uint64, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
     "paella_sample_tail_ex": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, c_float, c_float, c_int, c_void_p,
-                                      c_uint64, c_void_p, c_uint64, c_int64, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
+                                      c_uint64, c_void_p, c_uint64, c_int64, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
+    "paella_start_tokens": (c_int, [c_uint64, c_void_p, c_int64, c_void_p, c_int, c_int64, c_void_p, c_void_p]),
     "paella_add_noise": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint64, c_uint64, c_int, c_int,
                                  c_int64, c_void_p, c_void_p, c_void_p]),
     "paella_vqgan_create": (c_int, [POINTER(VqganConfig), POINTER(c_void_p)]),
@@ -76,8 +77,6 @@ SIGNATURES = {
                                     c_void_p, c_size_t, c_void_p]),
     "paella_vqgan_quantize_rows": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "paella_vqgan_lookup_rows": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
-    "paella_prof_enable": (c_int, [c_int]),
-    "paella_prof_collect": (c_int, [POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int64)]),
     "paella_set_gemm_precision": (c_int, [c_int]),
     "paella_get_gemm_precision": (c_int, []),
     "paella_op_gemm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
@@ -92,11 +91,14 @@ SIGNATURES = {
 
 # exported for tests / tools only; declared in paella_amd/csrc/test_hooks.h, not in the public header
 TEST_HOOKS = {
+    "paella_prof_enable": (c_int, [c_int]),
+    "paella_prof_collect": (c_int, [POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int64)]),
     "paella_test_register_weight": (c_int, [c_void_p, c_size_t, c_int]),
     "paella_test_launch_chain": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     "paella_test_attention_variant": (c_int, [c_int]),
     "paella_test_gemm_dma": (c_int, [c_int]),
     "paella_test_gemm_raster": (c_int, [c_int]),
+    "paella_test_tail_scores": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, c_float, c_float, c_uint64, c_uint64, c_int64, c_void_p, c_void_p]),
     "paella_test_gemm_prologue": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,
                                           c_void_p, c_size_t, c_void_p]),
 }

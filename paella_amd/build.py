@@ -12,7 +12,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 SOURCES = ["gemm.hip", "gemm_bf16.hip", "elementwise.hip", "dwconv.hip", "attention.hip", "tail.hip", "vqgan.hip", "model.hip", "vqmodel.hip"]
-HEADERS = ["common.h", "internal.h", "gemm_device.h", "test_hooks.h", os.path.join("..", "..", "include", "paella_hip.h")]
+HEADERS = ["common.h", "internal.h", "gemm_device.h", "philox.h", "test_hooks.h", os.path.join("..", "..", "include", "paella_hip.h")]
 LIB = os.path.join(CSRC, "libpaella_hip.so")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]

@@ -79,6 +79,7 @@ struct FusedTail {
     const uint64_t* seed_ptr;    // optional device-resident seed word added to seed
     uint64_t offset;
     int64_t row_offset;
+    const int64_t* row_offset_ptr;  // optional device-resident word added to row_offset (a captured graph replayed for another batch shard)
     float* part_score;           // [M, tiles_n]
     int* part_idx;               // [M, tiles_n]
 };
@@ -201,6 +202,7 @@ struct TailArgs {
     uint64_t seed; uint64_t offset;
     int64_t row_offset;           // Philox counters use row + row_offset: a batch shard [lo, hi) passes lo * H * W and draws the noise of its GLOBAL rows
     const uint64_t* seed_ptr;     // optional device-resident seed (added to `seed`): lets a captured HIP graph be replayed with new noise
+    const int64_t* row_offset_ptr;  // optional device-resident word added to row_offset: the same graph replayed for another batch shard
     const int64_t* init_noise;    // renoise source or null (no renoise)
     const float* mask_u;          // [rows] U[0,1) (parity mode) or null -> Philox
     float t_next;                 // uniform over the batch inside sample()
@@ -208,6 +210,9 @@ struct TailArgs {
     int64_t* sampled_out;         // [rows] pre-renoise draw (optional, may be null)
 };
 int launch_sample_tail(const TailArgs& a, hipStream_t stream);
+// start tokens of the counter-based mode: out[i] = Philox(seed (+ *seed_ptr), i + row_offset (+ *row_offset_ptr)) % num_labels
+int launch_start_tokens(uint64_t seed, const uint64_t* seed_ptr, int64_t row_offset, const int64_t* row_offset_ptr, int num_labels, int64_t n,
+                        int64_t* out, hipStream_t stream);
 
 // add_noise (reference src/modules.py:277-283)
 int launch_add_noise(const int64_t* x, const float* t, const int64_t* mask_in, const int64_t* random_x,

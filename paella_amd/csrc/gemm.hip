@@ -409,6 +409,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 &
 #pragma clang fp contract(off)
             const FusedTail& ft = g.ft;
             const uint64_t seed = ft.seed + (ft.seed_ptr ? *ft.seed_ptr : 0ull);
+            const int64_t row_off = ft.row_offset + (ft.row_offset_ptr ? *ft.row_offset_ptr : 0);
             const int L4 = g.N >> 2;
             float* s_score = smem + 2 * TILE_FLOATS + 16;
             int* s_idx = reinterpret_cast<int*>(s_score + BM * WN);
@@ -429,7 +430,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 &
                             for (int e = 0; e < 4; ++e) argmax_update(best, best_i, v[e], nn + e);
                         } else {
                             uint32_t rb[4];
-                            philox4x32(seed, (uint64_t)(m + ft.row_offset) * L4 + (nn >> 2), ft.offset, rb);
+                            philox4x32(seed, (uint64_t)(m + row_off) * L4 + (nn >> 2), ft.offset, rb);
 #pragma unroll
                             for (int e = 0; e < 4; ++e) argmax_update(best, best_i, tail_score_gumbel(v[e], ft.temperature, log_exp1(rb[e])), nn + e);
                         }
@@ -818,8 +819,10 @@ static GemmProf g_prof;
 
 static int launch_gemm_cfg_impl(const GemmArgs& g, int cfg, int splitk, void* ws, size_t ws_bytes, hipStream_t st);
 
-int launch_gemm_cfg(const GemmArgs& g, int cfg, int splitk, void* ws, size_t ws_bytes, hipStream_t st) {
-    if (!g_prof.on) return launch_gemm_cfg_impl(g, cfg, splitk, ws, ws_bytes, st);
+// every dense-contraction launch -- the head GEMM with the fused tail included -- goes through this bracket
+template <typename F>
+static int prof_bracket(const GemmArgs& g, hipStream_t st, bool stores_c, F&& launch) {
+    if (!g_prof.on) return launch();
     if (g_prof.used + 2 > g_prof.pool.size()) {
         for (int i = 0; i < 2; ++i) {
             hipEvent_t e;
@@ -829,12 +832,16 @@ int launch_gemm_cfg(const GemmArgs& g, int cfg, int splitk, void* ws, size_t ws_
     }
     hipEvent_t e0 = g_prof.pool[g_prof.used], e1 = g_prof.pool[g_prof.used + 1];
     HIP_CHECK_RET(hipEventRecord(e0, st));
-    const int rc = launch_gemm_cfg_impl(g, cfg, splitk, ws, ws_bytes, st);
+    const int rc = launch();
     HIP_CHECK_RET(hipEventRecord(e1, st));
     g_prof.used += 2;
     g_prof.flops.push_back(2.0 * g.M * g.N * g.K);
-    g_prof.bytes.push_back(4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N));
+    g_prof.bytes.push_back(4.0 * ((double)g.M * g.K + (double)g.N * g.K + (stores_c ? (double)g.M * g.N : 0.0)));
     return rc;
+}
+
+int launch_gemm_cfg(const GemmArgs& g, int cfg, int splitk, void* ws, size_t ws_bytes, hipStream_t st) {
+    return prof_bracket(g, st, true, [&]() { return launch_gemm_cfg_impl(g, cfg, splitk, ws, ws_bytes, st); });
 }
 
 extern "C" int paella_prof_enable(int on) {
@@ -995,7 +1002,11 @@ int gemm_tail_tiles_n(int M, int N) {
     const int BN = tc.wn * tc.tn * 16;
     return (N + BN - 1) / BN;
 }
+static int launch_gemm_tail_impl(const GemmArgs& g, hipStream_t st);
 int launch_gemm_tail(const GemmArgs& g, hipStream_t st) {
+    return prof_bracket(g, st, false, [&]() { return launch_gemm_tail_impl(g, st); });  // (no logits are stored: M*N bytes not counted)
+}
+static int launch_gemm_tail_impl(const GemmArgs& g, hipStream_t st) {
     if (g.M <= 0 || g.N <= 0) return PAELLA_OK;
     if ((g.K & 3) || (g.N & 3) || (g.lda & 3) || (g.ldw & 3) || g.a_scale || g.ln_stats || !g.ft.part_score || !g.ft.part_idx) {
         paella_set_error("gemm_tail: unsupported arguments (M=%d N=%d K=%d)", g.M, g.N, g.K);

@@ -418,6 +418,10 @@ static void carve_forward(const paella_unet* m, Arena& a, int B, int H, int W, i
     f.splitk = a.take(kSplitKBudget / sizeof(float));  // FIRST: its ticket header sits at a fixed offset (paella_workspace_init)
     size_t hmax = (size_t)B * H * W * c.c_out;
     size_t gmax = (size_t)B * H * W * c.c_out;
+    {   // the fused head + tail parks one (score, label) per row and column tile in f.g: [rows, tiles_n] x 2 with tiles of >= 64 labels
+        const size_t part = (size_t)B * H * W * 2 * (((size_t)c.num_labels + 63) / 64);
+        if (part > gmax) gmax = part;
+    }
     const size_t emb = (size_t)level_rows(m, B, H, W, 0) * c.c_in * p2;
     if (emb > hmax) hmax = emb;
     for (int l = 0; l < c.n_levels; ++l) {
@@ -783,16 +787,18 @@ static int unet_forward_impl(paella_unet* m, const int64_t* tokens, const float*
         if (!tail) {
             // same tile config as the fused-tail launch below (one whole tile per workgroup, no K split): the two paths produce
             // bit-identical logits, hence identical tokens
-            RET_IF(launch_gemm_cfg(go, gemm_tail_config((int)nt, c.num_labels), 1, f.splitk, kSplitKBudget, st));
+            // (the opt-in bf16 fast mode has no parity contract with the fused path: it keeps the heuristic, which routes to the bf16 kernel)
+            if (gemm_precision() == 1) RET_IF(launch_gemm(go, f.splitk, kSplitKBudget, st));
+            else RET_IF(launch_gemm_cfg(go, gemm_tail_config((int)nt, c.num_labels), 1, f.splitk, kSplitKBudget, st));
         } else {
             // out_mapper fused with the sampling tail (reference src/utils.py:44-50 materialises the logits; here they never leave
             // the registers): per row and column tile the best (score, label) lands in f.g (free after the LayerNorm above)
             const int tn = gemm_tail_tiles_n((int)nt, c.num_labels);
-            if ((size_t)tn * 2 > (size_t)c.c_out) { paella_set_error("fused tail: partial buffer does not fit (tiles_n=%d, c_out=%d)", tn, c.c_out); return PAELLA_ERR_ARG; }
+            if (tn > (c.num_labels + 63) / 64) { paella_set_error("internal: fused tail tiles narrower than 64 labels (tiles_n=%d)", tn); return PAELLA_ERR_STATE; }
             if (tail->rows != nt || tail->L != c.num_labels) { paella_set_error("fused tail: row / label count mismatch"); return PAELLA_ERR_ARG; }
             go.C = nullptr;
             go.ft.temperature = tail->temperature; go.ft.mode = tail->mode; go.ft.seed = tail->seed; go.ft.seed_ptr = tail->seed_ptr;
-            go.ft.offset = tail->offset; go.ft.row_offset = tail->row_offset;
+            go.ft.offset = tail->offset; go.ft.row_offset = tail->row_offset; go.ft.row_offset_ptr = tail->row_offset_ptr;
             go.ft.part_score = f.g;
             go.ft.part_idx = reinterpret_cast<int*>(f.g + (size_t)nt * tn);
             RET_IF(launch_gemm_tail(go, st));
@@ -815,8 +821,8 @@ extern "C" int paella_unet_forward_shared(paella_unet* m, const int64_t* tokens,
 extern "C" int paella_unet_forward_sample(paella_unet* m, const int64_t* tokens, const float* r, const void* cond, int B, int n_unique,
                                           float mix_c, float mix_u, int H, int W, int S, const float* attn_weights, int n_attn_weights,
                                           float temperature, int mode, uint64_t seed, const uint64_t* seed_ptr, uint64_t offset,
-                                          int64_t row_offset, const int64_t* init_noise, float t_next, int64_t* tokens_out,
-                                          void* ws, size_t ws_bytes, void* stream) {
+                                          int64_t row_offset, const int64_t* row_offset_ptr, const int64_t* init_noise, float t_next,
+                                          int64_t* tokens_out, void* ws, size_t ws_bytes, void* stream) {
     if (!tokens_out) { paella_set_error("null argument"); return PAELLA_ERR_ARG; }
     const bool mix = mix_c != 0.f || mix_u != 0.f;
     if (!mix && n_unique != B) { paella_set_error("forward_sample without a guidance mix needs n_unique == B (separate cond / uncond logits take the unfused path)"); return PAELLA_ERR_ARG; }
@@ -827,7 +833,7 @@ extern "C" int paella_unet_forward_sample(paella_unet* m, const int64_t* tokens,
     a.rows = (int64_t)(mix ? n_unique : B) * H * W;
     a.L = m ? m->cfg.num_labels : 0;
     a.cfg = 1.f; a.one_minus_cfg = 0.f; a.temperature = temperature; a.mode = mode; a.noise_q = nullptr; a.seed = seed; a.seed_ptr = seed_ptr;
-    a.offset = offset; a.row_offset = row_offset; a.init_noise = init_noise; a.mask_u = nullptr; a.t_next = t_next;
+    a.offset = offset; a.row_offset = row_offset; a.row_offset_ptr = row_offset_ptr; a.init_noise = init_noise; a.mask_u = nullptr; a.t_next = t_next;
     a.tokens_out = tokens_out; a.sampled_out = nullptr;
     return unet_forward_impl(m, tokens, r, cond, B, n_unique, mix_c, mix_u, H, W, S, attn_weights, n_attn_weights, nullptr, &a, ws, ws_bytes, stream);
 }
@@ -837,15 +843,15 @@ extern "C" int paella_unet_forward_sample(paella_unet* m, const int64_t* tokens,
 // ---------------------------------------------------------------------------
 extern "C" int paella_sample_tail_ex(const float* logits_c, const float* logits_u, int64_t rows, int L, float cfg, float one_minus_cfg,
                                      float temperature, int mode, const float* noise_q, uint64_t seed, const uint64_t* seed_ptr,
-                                     uint64_t offset, int64_t row_offset, const int64_t* init_noise, const float* mask_u, float t_next,
-                                     int64_t* tokens_out, int64_t* sampled_out, void* stream) {
+                                     uint64_t offset, int64_t row_offset, const int64_t* row_offset_ptr, const int64_t* init_noise, const float* mask_u,
+                                     float t_next, int64_t* tokens_out, int64_t* sampled_out, void* stream) {
     if (!logits_c || !tokens_out) { paella_set_error("null argument"); return PAELLA_ERR_ARG; }
     if (mode == 0 && !(temperature > 0.f)) { paella_set_error("temperature must be > 0 in categorical mode (use mode=1 for argmax)"); return PAELLA_ERR_ARG; }
     if (row_offset < 0) { paella_set_error("row_offset must be >= 0"); return PAELLA_ERR_ARG; }
     TailArgs a;
     a.logits_c = logits_c; a.logits_u = logits_u; a.rows = rows; a.L = L; a.cfg = cfg; a.one_minus_cfg = one_minus_cfg;
     a.temperature = temperature; a.mode = mode; a.noise_q = noise_q; a.seed = seed; a.seed_ptr = seed_ptr; a.offset = offset;
-    a.row_offset = row_offset;
+    a.row_offset = row_offset; a.row_offset_ptr = row_offset_ptr;
     a.init_noise = init_noise; a.mask_u = mask_u; a.t_next = t_next; a.tokens_out = tokens_out; a.sampled_out = sampled_out;
     return launch_sample_tail(a, (hipStream_t)stream);
 }
@@ -854,8 +860,13 @@ extern "C" int paella_sample_tail(const float* logits_c, const float* logits_u, 
                                   float temperature, int mode, const float* noise_q, uint64_t seed, uint64_t offset,
                                   const int64_t* init_noise, const float* mask_u, float t_next, int64_t* tokens_out,
                                   int64_t* sampled_out, void* stream) {
-    return paella_sample_tail_ex(logits_c, logits_u, rows, L, cfg, one_minus_cfg, temperature, mode, noise_q, seed, nullptr, offset, 0,
+    return paella_sample_tail_ex(logits_c, logits_u, rows, L, cfg, one_minus_cfg, temperature, mode, noise_q, seed, nullptr, offset, 0, nullptr,
                                  init_noise, mask_u, t_next, tokens_out, sampled_out, stream);
+}
+
+extern "C" int paella_start_tokens(uint64_t seed, const uint64_t* seed_ptr, int64_t row_offset, const int64_t* row_offset_ptr, int num_labels,
+                                   int64_t n, int64_t* tokens_out, void* stream) {
+    return launch_start_tokens(seed, seed_ptr, row_offset, row_offset_ptr, num_labels, n, tokens_out, (hipStream_t)stream);
 }
 
 extern "C" int paella_add_noise(const int64_t* x, const float* t, const int64_t* mask_in, const int64_t* random_x, const float* rand_u,

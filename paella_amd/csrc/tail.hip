@@ -22,6 +22,8 @@ __device__ __forceinline__ float mix_logit(float lc, float lu, float cfg, float 
 }
 
 // renoise (src/utils.py:54 -> src/modules.py:277-283 with random_x = init_noise): u <= t_next ? init_noise : token
+__device__ __forceinline__ int64_t tail_row_offset(const TailArgs& a) { return a.row_offset + (a.row_offset_ptr ? *a.row_offset_ptr : 0); }
+
 __device__ __forceinline__ int64_t renoise_token(const TailArgs& a, uint64_t seed, int64_t row, int64_t tok) {
     if (a.init_noise) {
         float u;
@@ -29,7 +31,7 @@ __device__ __forceinline__ int64_t renoise_token(const TailArgs& a, uint64_t see
             u = a.mask_u[row];
         } else {
             uint32_t rb[4];
-            philox4x32(seed ^ 0x5bd1e9955bd1e995ull, (uint64_t)(row + a.row_offset), a.offset, rb);
+            philox4x32(seed ^ 0x5bd1e9955bd1e995ull, (uint64_t)(row + tail_row_offset(a)), a.offset, rb);
             u = u01_half_open(rb[0]);
         }
         if (u <= a.t_next) tok = a.init_noise[row];
@@ -49,6 +51,7 @@ __global__ __launch_bounds__(256) void sample_tail_kernel(TailArgs a) {
     const bool argmax_mode = a.mode == 1;
     const uint64_t seed = a.seed + (a.seed_ptr ? *a.seed_ptr : 0ull);
     const float* nq = a.noise_q ? a.noise_q + row * L : nullptr;
+    const int64_t row_off = tail_row_offset(a);
 
     // pass 1 (explicit-noise parity mode only): max of x = mix / T for the softmax numerator exp(x - max).
     // The argmax and the counter-based mode never need it: argmax(x - log q) is invariant to a per-row shift.
@@ -81,7 +84,7 @@ __global__ __launch_bounds__(256) void sample_tail_kernel(TailArgs a) {
                 q = *reinterpret_cast<const f32x4*>(nq + i4 * 4);
             } else {
                 uint32_t rb[4];
-                philox4x32(seed, (uint64_t)(row + a.row_offset) * L4 + i4, a.offset, rb);
+                philox4x32(seed, (uint64_t)(row + row_off) * L4 + i4, a.offset, rb);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) q[e] = log_exp1(rb[e]);
             }
@@ -163,6 +166,34 @@ int launch_sample_tail(const TailArgs& a, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------
+// Start tokens of the counter-based noise mode: the reference draws randint(0, num_labels, (B, H, W)) from torch's global generator
+// (src/utils.py:37), a stream that cannot be sharded.  Here token i of the GLOBAL grid is a function of (seed, i) alone, so a batch
+// shard draws exactly the start tokens the unsharded call gives its rows, at O(shard) cost, and -- seed and row offset being optional
+// device-resident words -- from inside a captured graph.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void start_tokens_kernel(uint64_t seed, const uint64_t* __restrict__ seed_ptr, int64_t row_offset,
+                                                           const int64_t* __restrict__ row_offset_ptr, int num_labels, int64_t n,
+                                                           int64_t* __restrict__ out) {
+    const uint64_t s = (seed + (seed_ptr ? *seed_ptr : 0ull)) ^ 0x9e3779b97f4a7c15ull;
+    const int64_t off = row_offset + (row_offset_ptr ? *row_offset_ptr : 0);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        uint32_t rb[4];
+        philox4x32(s, (uint64_t)(i + off), ~0ull, rb);
+        out[i] = (int64_t)((((uint64_t)rb[0] << 32) | rb[1]) % (uint64_t)num_labels);
+    }
+}
+int launch_start_tokens(uint64_t seed, const uint64_t* seed_ptr, int64_t row_offset, const int64_t* row_offset_ptr, int num_labels, int64_t n,
+                        int64_t* out, hipStream_t st) {
+    if (n <= 0) return PAELLA_OK;
+    if (!out || num_labels <= 0 || row_offset < 0) { paella_set_error("start_tokens: bad arguments"); return PAELLA_ERR_ARG; }
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(start_tokens_kernel, dim3((unsigned)blocks), dim3(256), 0, st, seed, seed_ptr, row_offset, row_offset_ptr, num_labels, n, out);
+    LAUNCH_CHECK_RET();
+    return PAELLA_OK;
+}
+
+// ---------------------------------------------------------------------------
 // add_noise: mask = (U[0,1) <= t[b]).long(); x*(1-mask) + random_x*mask   (int64 arithmetic as written)
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void add_noise_kernel(const int64_t* __restrict__ x, const float* __restrict__ t,
@@ -194,6 +225,41 @@ int launch_add_noise(const int64_t* x, const float* t, const int64_t* mask_in, c
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(add_noise_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, t, mask_in, random_x, rand_u, seed,
                        offset, num_labels, total, per_sample, x_out, mask_out);
+    LAUNCH_CHECK_RET();
+    return PAELLA_OK;
+}
+
+// ---------------------------------------------------------------------------
+// test hook (test_hooks.h): the scores the counter-based tail maximises, written out -- score[row][i] = mix(l_c, l_u)[i] / T - log q_i
+// with exactly the kernels' arithmetic and Philox counters.  Lets a test classify a differing token by the decision margin
+// (top-1 minus top-2 score) instead of bounding a mismatch count.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tail_scores_kernel(TailArgs a, float* __restrict__ scores) {
+    const int64_t row = blockIdx.x;
+    const int L = a.L, L4 = L >> 2;
+    const float* lc = a.logits_c + row * L;
+    const float* lu = a.logits_u ? a.logits_u + row * L : nullptr;
+    const bool has_u = lu != nullptr;
+    const uint64_t seed = a.seed + (a.seed_ptr ? *a.seed_ptr : 0ull);
+    const int64_t row_off = tail_row_offset(a);
+    for (int i4 = threadIdx.x; i4 < L4; i4 += 256) {
+        const f32x4 c = *reinterpret_cast<const f32x4*>(lc + i4 * 4);
+        const f32x4 u = has_u ? *reinterpret_cast<const f32x4*>(lu + i4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        uint32_t rb[4];
+        philox4x32(seed, (uint64_t)(row + row_off) * L4 + i4, a.offset, rb);
+        f32x4 s;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[e] = tail_score_gumbel(mix_logit(c[e], u[e], a.cfg, a.one_minus_cfg, has_u), a.temperature, log_exp1(rb[e]));
+        *reinterpret_cast<f32x4*>(scores + row * L + i4 * 4) = s;
+    }
+}
+extern "C" int paella_test_tail_scores(const float* logits_c, const float* logits_u, int64_t rows, int L, float cfg, float one_minus_cfg,
+                                       float temperature, uint64_t seed, uint64_t offset, int64_t row_offset, float* scores_out, void* stream) {
+    if (!logits_c || !scores_out || (L & 3) || rows <= 0 || rows > 0x7fffffff || !(temperature > 0.f)) { paella_set_error("tail_scores: bad arguments"); return PAELLA_ERR_ARG; }
+    TailArgs a = {};
+    a.logits_c = logits_c; a.logits_u = logits_u; a.rows = rows; a.L = L; a.cfg = cfg; a.one_minus_cfg = one_minus_cfg; a.temperature = temperature;
+    a.seed = seed; a.offset = offset; a.row_offset = row_offset;
+    hipLaunchKernelGGL(tail_scores_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, a, scores_out);
     LAUNCH_CHECK_RET();
     return PAELLA_OK;
 }

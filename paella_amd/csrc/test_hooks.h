@@ -22,6 +22,15 @@ int paella_test_gemm_prologue(const float* A, const float* W, float* C, int M, i
 int paella_test_gemm_dma(int on);
 /* tile rows per rasterisation group of the GEMM (default 8); 0 = plain m-fastest tile order (A/B) */
 int paella_test_gemm_raster(int gm);
+/* Measurement hook (bench.py roofline line): when enabled, EVERY dense-contraction launch (the head GEMM with the fused sampling tail included)
+ * is bracketed by HIP events on its stream; collect() returns the summed duration, algorithmic FLOPs and bytes since enable(1).  Process-wide,
+ * single host thread (the events live in a plain vector). */
+int paella_prof_enable(int on);
+int paella_prof_collect(double* total_ms, double* total_flops, double* total_bytes, long long* launches);
+/* scores_out [rows, L] = the Gumbel-max scores of the counter-based sampling tail (mix(l_c, l_u) / T - log q, the kernels' own arithmetic and
+ * Philox counters): tests classify a differing token by the decision margin between the two best scores of its row */
+int paella_test_tail_scores(const float* logits_c, const float* logits_u, long long rows, int L, float cfg, float one_minus_cfg, float temperature,
+                            unsigned long long seed, unsigned long long offset, long long row_offset, float* scores_out, void* stream);
 #ifdef __cplusplus
 }
 #endif

@@ -71,11 +71,41 @@ def conditioning_layout(input_sets):
     return descs, numel
 
 
-def broadcast_conditioning(input_sets, src=0, device=None, group=None, layout=None):
+def cond_spec_layout(model, B, S_byt5=0, S_byt5_uncond=None, clip=True, n_clip_image=0, sets=2):
+    """The layout of [model_inputs, unconditional_inputs] derived from what every rank knows WITHOUT seeing the tensors: the model's
+    embedding widths, the global batch, the ByT5 sequence lengths and which CLIP inputs are present (fixed-shape serving).  Pass the
+    result as `layout=` to sample_sharded / broadcast_conditioning: the conditioning then travels in exactly one collective."""
+    cfg = model._cfg
+    out, numel = [], 0
+    for i in range(sets):
+        S = S_byt5 if (i == 0 or S_byt5_uncond is None) else S_byt5_uncond
+        d = [("byt5", (B, S, cfg["byt5_embd"]))]
+        numel += B * S * cfg["byt5_embd"]
+        d.append(("clip", (B, cfg["clip_embd"]) if clip else None))
+        numel += B * cfg["clip_embd"] if clip else 0
+        if n_clip_image == 0:
+            d.append(("clip_image", None))
+        elif n_clip_image == 1:
+            d.append(("clip_image", (B, cfg["clip_embd"])))
+        else:
+            d.append(("clip_image", [(B, cfg["clip_embd"])] * n_clip_image))
+        numel += n_clip_image * B * cfg["clip_embd"]
+        out.append(d)
+    return out, numel
+
+
+def _pack_seed(seed, device):
+    """An int64 seed as two fp32 words (bit pattern preserved): it rides at the end of the flat conditioning buffer."""
+    return torch.tensor([int(seed)], dtype=torch.int64).view(torch.float32).to(device)
+
+
+def broadcast_conditioning(input_sets, src=0, device=None, group=None, layout=None, seed=None, with_seed=False):
     """Broadcast a list of conditioning dicts (e.g. [model_inputs, unconditional_inputs]) from `src` with ONE
     tensor collective.  Non-source ranks pass None.  Without `layout` the shapes travel first in one small object
-    broadcast (which synchronises host and device); with `layout` = conditioning_layout(...) known on every rank the
-    call is a single asynchronous RCCL broadcast on the current stream."""
+    broadcast (which synchronises host and device; a receiver cannot size its buffer otherwise); with `layout` =
+    conditioning_layout(...) / cond_spec_layout(...) known on every rank the call is a single asynchronous RCCL broadcast on
+    the current stream.  with_seed=True appends the source's Philox seed (`seed`, or a fresh one) to the SAME buffer and
+    returns (sets, seed): seed agreement costs no collective of its own."""
     rank = dist.get_rank(group)
     meta = [None]
     flat = None
@@ -88,8 +118,13 @@ def broadcast_conditioning(input_sets, src=0, device=None, group=None, layout=No
         device = all_tensors[0].device if device is None else torch.device(device)
         flat = torch.cat([t.reshape(-1).float() for t in all_tensors]).to(device) if all_tensors else torch.zeros(0, device=device)
         meta = [(descs, flat.numel())]
-        if layout is not None and (layout[1] != flat.numel() or layout[0] != descs):
+        if layout is not None and (layout[1] != flat.numel() or [list(map(tuple, d)) for d in layout[0]] != [list(map(tuple, d)) for d in descs]):
             raise ValueError("conditioning does not match the agreed layout")
+        if with_seed:
+            if seed is None:
+                from .sampling import fresh_seed
+                seed = fresh_seed()
+            flat = torch.cat([flat, _pack_seed(seed, flat.device)])
     if layout is None:
         dist.broadcast_object_list(meta, src=src, group=group)
         descs, numel = meta[0]
@@ -98,8 +133,11 @@ def broadcast_conditioning(input_sets, src=0, device=None, group=None, layout=No
     if rank != src:
         if device is None:
             raise ValueError("non-source ranks must pass device")
-        flat = torch.empty(numel, dtype=torch.float32, device=device)
+        flat = torch.empty(numel + (2 if with_seed else 0), dtype=torch.float32, device=device)
     dist.broadcast(flat, src=src, group=group)
+    if with_seed:
+        seed = int(flat[numel:numel + 2].clone().view(torch.int64).item())
+        flat = flat[:numel]
     out, off = [], 0
     for d in descs:
         n = 0
@@ -111,7 +149,7 @@ def broadcast_conditioning(input_sets, src=0, device=None, group=None, layout=No
                 n += m
         out.append(_unflatten(flat[off:off + n], d, flat.device))
         off += n
-    return out
+    return (out, seed) if with_seed else out
 
 
 def shard_inputs(inputs, lo, hi):
@@ -144,9 +182,12 @@ def agree_on_seed(seed, src=0, device=None, group=None):
 
 
 def sample_sharded(model, model_inputs, unconditional_inputs, latent_shape, src=0, group=None, gather=False, noise="philox", seed=None,
-                   **kwargs):
+                   layout=None, **kwargs):
     """Batch-sharded `sample`: broadcast the conditioning once, sample this rank's rows, optionally all_gather.
     `model_inputs` / `unconditional_inputs` are needed on rank `src` only.  kwargs go to paella_amd.sample.
+    Collectives: with `layout=` (conditioning_layout / cond_spec_layout, computable on every rank) exactly ONE -- the packed
+    broadcast, which also carries the Philox seed; without it one small shape handshake precedes that broadcast (a receiver
+    cannot size its buffer otherwise).  Never a separate seed collective.
     With the counter-based noise (default here) every random number -- start tokens, categorical draws, renoise mask -- is
     keyed by (seed, GLOBAL row, step), so the concatenation of the shards equals the unsharded `sample(..., noise="philox",
     seed=seed)` bit for bit, whatever the world size.  noise="torch" consumes each rank's own torch generator
@@ -154,14 +195,13 @@ def sample_sharded(model, model_inputs, unconditional_inputs, latent_shape, src=
     from .sampling import sample
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     device = next(model.parameters()).device
-    cond, uncond = broadcast_conditioning([model_inputs, unconditional_inputs] if rank == src else None, src=src,
-                                          device=device, group=group)
+    philox = noise == "philox"
+    res = broadcast_conditioning([model_inputs, unconditional_inputs] if rank == src else None, src=src, device=device, group=group,
+                                 layout=layout, seed=seed, with_seed=philox)
+    (cond, uncond), seed = res if philox else (res, seed)
     B, H, W = latent_shape
     lo, hi = shard_bounds(B, rank, world)
-    shard = None
-    if noise == "philox":
-        seed = agree_on_seed(seed, src=src, device=device, group=group)
-        shard = (lo, B)
+    shard = (lo, B) if philox else None
     local = None
     if hi > lo:
         local = sample(model, shard_inputs(cond, lo, hi), (hi - lo, H, W), unconditional_inputs=shard_inputs(uncond, lo, hi),

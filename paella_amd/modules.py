@@ -54,6 +54,20 @@ class _Block(_Holder):
         self.kind = kind
 
 
+class _InferenceOnly(torch.autograd.Function):
+    """Marks an eval-mode result of the HIP engine as non-differentiable WITH a readable failure: the engine keeps no activations
+    and has no backward kernels, so `loss.backward()` through an eval-mode forward raises here and names the fix."""
+
+    @staticmethod
+    def forward(ctx, out, anchor):
+        return out.view_as(out)
+
+    @staticmethod
+    def backward(ctx, grad):
+        raise RuntimeError("paella_amd.Paella was evaluated in eval mode (the hand-written HIP inference engine, which has no backward); "
+                           "call model.train() before the forward for the differentiable path (paella_amd/training.py)")
+
+
 class CondCache:
     """Device-resident result of `Paella.prepare_cond` (K/V of the conditioning rows for every AttnBlock)."""
 
@@ -375,7 +389,7 @@ class Paella(nn.Module):
         return out.permute(0, 3, 1, 2)
 
     def forward_sample(self, x, r, cond, out, *, temperature, argmax=False, seed=0, seed_dev=None, offset=0, row_offset=0,
-                       init_noise=None, t_next=0.0, cfg_mix=None, attn_weights=None, ws=None):
+                       row_offset_dev=None, init_noise=None, t_next=0.0, cfg_mix=None, attn_weights=None, ws=None):
         """One whole sampling step in the counter-based noise mode (src/utils.py:43-54): the denoiser evaluation with the head
         GEMM and the sampling tail FUSED -- the [B, num_labels, H, W] logits are never materialised.  x int64 [Bx,H,W], r [Bx];
         cfg_mix=(a, b) with cond.B == 2*Bx folds classifier-free guidance through the head (as forward_prepared); without it
@@ -400,7 +414,7 @@ class Paella(nn.Module):
             ws = self._workspace(lib.paella_unet_workspace_bytes(h, B, H, W, cond.S), ws)
             _lib.check(lib.paella_unet_forward_sample(h, _lib.ptr(x), _lib.ptr(r), _lib.ptr(cond.buf), B, nu, mix[0], mix[1], H, W, cond.S,
                                                       _lib.ptr(aw), 0 if aw is None else aw.numel(), float(temperature), 1 if argmax else 0,
-                                                      int(seed), _lib.ptr(seed_dev), int(offset), int(row_offset), _lib.ptr(init_noise),
+                                                      int(seed), _lib.ptr(seed_dev), int(offset), int(row_offset), _lib.ptr(row_offset_dev), _lib.ptr(init_noise),
                                                       float(t_next), _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)))
         return out
 
@@ -417,7 +431,14 @@ class Paella(nn.Module):
         if x_cat is not None:
             x = torch.cat([x, x_cat], dim=1)
         cond = self.prepare_cond(byt5, clip, clip_image)
-        return self.forward_prepared(x, r, cond, attn_weights=kwargs.get("attn_weights"))
+        out = self.forward_prepared(x, r, cond, attn_weights=kwargs.get("attn_weights"))
+        if torch.is_grad_enabled():
+            # like the reference module's, an eval-mode result computed with gradients enabled is attached to the parameters -- but
+            # backpropagating through it fails with a message that names model.train() instead of 'does not require grad'
+            anchor = next((p for p in self.parameters() if p.requires_grad), None)
+            if anchor is not None:
+                out = _InferenceOnly.apply(out, anchor)
+        return out
 
     # ------------------------------------------------------------------ add_noise / loss weight
     def add_noise(self, x, t, mask=None, random_x=None):

@@ -75,30 +75,37 @@ def _cat_inputs(a, b):
 
 
 def _tail(logits_c, logits_u, rows, L, cfg, omc, temperature, mode, noise_q, seed, offset, init_noise, mask_u, t_next, out,
-          seed_dev=None, row_offset=0):
+          seed_dev=None, row_offset=0, row_offset_dev=None):
     lib = _lib.load()
     dev = logits_c.device
     with torch.cuda.device(dev):
         _lib.check(lib.paella_sample_tail_ex(_lib.ptr(logits_c), _lib.ptr(logits_u), rows, L, cfg, omc, temperature, mode,
-                                             _lib.ptr(noise_q), seed, _lib.ptr(seed_dev), offset, row_offset, _lib.ptr(init_noise),
-                                             _lib.ptr(mask_u), t_next, _lib.ptr(out), None, _lib.stream_ptr(dev)))
+                                             _lib.ptr(noise_q), seed, _lib.ptr(seed_dev), offset, row_offset, _lib.ptr(row_offset_dev),
+                                             _lib.ptr(init_noise), _lib.ptr(mask_u), t_next, _lib.ptr(out), None, _lib.stream_ptr(dev)))
 
 
 def fresh_seed():
     """A 62-bit seed drawn from torch's default (CPU) generator: reproducible under torch.manual_seed, different on every
-    call otherwise -- what `seed=None` means in the counter-based (Philox) noise mode."""
+    call otherwise -- what `seed=None` means in the counter-based (Philox) noise mode.  NOTE: this consumes one draw of torch's
+    global CPU generator per call (the reference's sample() consumes the global DEVICE generator instead, src/utils.py:37)."""
     return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
 
 
-def start_tokens(num_labels, shape, seed, device, shard=None):
-    """The start tokens of the counter-based noise mode: randint(0, num_labels) over the GLOBAL batch from a generator keyed by
-    `seed`, sliced to this shard's rows -- so a batch shard starts from exactly the tokens the unsharded call gives those rows
-    (the reference draws them with torch.randint on the global generator, src/utils.py:37; that stream cannot be sharded)."""
+def start_tokens(num_labels, shape, seed, device, shard=None, out=None, seed_dev=None, row_offset_dev=None):
+    """The start tokens of the counter-based noise mode (the reference draws torch.randint on the global generator,
+    src/utils.py:37 -- a stream that cannot be sharded): token i of the GLOBAL [total, H, W] grid is Philox(seed, i) mod
+    num_labels (paella_start_tokens), so a batch shard draws exactly its rows of the unsharded draw at O(shard) cost.
+    seed_dev / row_offset_dev: optional device-resident words added to seed / the row offset (a captured graph draws fresh
+    tokens for any seed and shard without host work)."""
     B, H, W = shape
-    lo, total = (0, B) if shard is None else (int(shard[0]), int(shard[1]))
-    gen = torch.Generator(device=device)
-    gen.manual_seed(int(seed) & (2 ** 63 - 1))
-    return torch.randint(0, num_labels, (total, H, W), device=device, generator=gen)[lo:lo + B].contiguous()
+    lo = 0 if shard is None else int(shard[0])
+    device = torch.device(device)
+    if out is None:
+        out = torch.empty(B, H, W, dtype=torch.int64, device=device)
+    with torch.cuda.device(device):
+        _lib.check(_lib.load().paella_start_tokens(int(seed), _lib.ptr(seed_dev), lo * H * W, _lib.ptr(row_offset_dev), int(num_labels),
+                                                   B * H * W, _lib.ptr(out), _lib.stream_ptr(device)))
+    return out
 
 
 def timestep_table(t_list, steps, B, device):
@@ -108,10 +115,11 @@ def timestep_table(t_list, steps, B, device):
 
 def _sample_core(model, model_inputs, unconditional_inputs, latent_shape, init_x, steps, renoise_steps, t_list, temperatures,
                  cfgs, device, noise="torch", seed=None, attn_weights=None, seed_dev=None, init_noise_buf=None, r_all=None, shard=None,
-                 ws=None, fused_tail=True):
+                 ws=None, fused_tail=True, row_offset_dev=None):
     """cfgs: per-step list of (cfg_fp32, one_minus_cfg_fp32) or None (no guidance at that step).
-    seed_dev / init_noise_buf / r_all: device-resident seed word, pre-drawn start tokens and the [steps, B] timestep table
-    (HIP-graph capture cannot upload from the host, see GraphSampler); ws: caller-owned workspace for every library call.
+    seed_dev / row_offset_dev / init_noise_buf / r_all: device-resident seed and row-offset words, a buffer for the start tokens
+    and the [steps, B] timestep table (HIP-graph capture cannot upload from the host, see GraphSampler); ws: caller-owned
+    workspace for every library call.
     shard = (lo, total): this call samples rows [lo, lo + B) of a global batch of `total`; with noise="philox" every random
     number is keyed by the GLOBAL row, so the shard reproduces those rows of the unsharded call bit for bit."""
     explicit = isinstance(noise, dict)  # parity tests: {"init_noise": [B,H,W], "q": [rows,L] per step, "u": [B,H,W] per step}
@@ -134,7 +142,9 @@ def _sample_core(model, model_inputs, unconditional_inputs, latent_shape, init_x
         raise ValueError("shard=(lo, total) needs noise='philox' (or explicit noise tensors): torch's generator stream cannot be sharded")
     row_offset = 0 if shard is None else int(shard[0]) * H * W
     with torch.inference_mode():
-        if init_noise_buf is not None:
+        if init_noise_buf is not None and philox:
+            init_noise = start_tokens(L, (B, H, W), seed, device, shard, out=init_noise_buf, seed_dev=seed_dev, row_offset_dev=row_offset_dev)
+        elif init_noise_buf is not None:
             init_noise = init_noise_buf
         elif explicit:
             init_noise = noise["init_noise"].to(device=device, dtype=torch.int64).contiguous()
@@ -172,7 +182,8 @@ def _sample_core(model, model_inputs, unconditional_inputs, latent_shape, init_x
                 # in place is safe: the token gather at the head of the forward and the token store at its tail are different kernels
                 # of one stream
                 model.forward_sample(sampled, r, cond_both if use_cfg else cond_c, out, temperature=temp if mode == 0 else 1.0, argmax=mode == 1,
-                                     seed=seed, seed_dev=seed_dev, offset=i, row_offset=row_offset, init_noise=init_noise if renoise else None,
+                                     seed=seed, seed_dev=seed_dev, offset=i, row_offset=row_offset, row_offset_dev=row_offset_dev,
+                                     init_noise=init_noise if renoise else None,
                                      t_next=t_list[i + 1] if renoise else 0.0, cfg_mix=cfgs[i] if use_cfg else None, attn_weights=attn_weights, ws=ws)
                 sampled = out
                 continue
@@ -215,7 +226,7 @@ def _sample_core(model, model_inputs, unconditional_inputs, latent_shape, init_x
             cfg, omc = cfgs[i] if use_cfg else (1.0, 0.0)
             _tail(lc, lu, rows, L, cfg, omc, temp if mode == 0 else 1.0, mode, noise_q, seed, i,
                   init_noise if renoise else None, mask_u, t_list[i + 1] if renoise else 0.0, out, seed_dev=seed_dev,
-                  row_offset=row_offset)
+                  row_offset=row_offset, row_offset_dev=row_offset_dev)
             sampled = out  # the tail never reads `sampled`, so one output buffer is enough (stream-ordered reuse)
     return sampled
 
@@ -271,8 +282,11 @@ class GraphSampler:
     Why: at batch 1 the path is ~3000 short kernels per image and eager launches are host-bound at ~2.8 us per kernel
     on this platform (tools/launch_floor.py), a graph replays the same kernels at ~1.6-1.8 us.  Arithmetic, kernels and
     results are identical to `sample(..., noise="philox")`; only the submission mechanism changes.  Per request the
-    conditioning tensors are copied into the graph's static input buffers, fresh start tokens are drawn with
-    torch.randint (as the reference does) and the Philox seed word in device memory is rewritten.
+    conditioning tensors are copied into the graph's static input buffers and two device words are rewritten: the Philox seed
+    and the GLOBAL row offset of this replay's batch shard.  Start tokens, categorical draws and renoise masks are all drawn
+    inside the graph as functions of (seed, global row, step): `sampler(seed=s, shard=(lo, total))` returns exactly rows
+    [lo, lo + B) of `sample(..., noise="philox", seed=s)` over the global batch (tests/test_gpu_sample.py).
+    seed=None draws a fresh seed from torch's global CPU generator (one draw per call; see fresh_seed).
     """
 
     def __init__(self, model, model_inputs, unconditional_inputs, latent_shape, steps=12, renoise_steps=11, temperature=(1.0, 0.2),
@@ -285,6 +299,7 @@ class GraphSampler:
                                                   for k, v in d.items()}
         self.cond, self.uncond = clone(model_inputs), clone(unconditional_inputs)
         self.seed_dev = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self.row_offset_dev = torch.zeros(1, dtype=torch.int64, device=self.device)  # lo * H * W of the shard being sampled
         self.init_noise = torch.zeros(self.shape, dtype=torch.int64, device=self.device)
         self.r_all = timestep_table(linspace_schedule(t_start, t_end, steps + 1), steps, self.shape[0], self.device)
         # The graph bakes raw pointers: it owns its workspaces (the modules' own scratch is dropped and reallocated whenever a
@@ -317,7 +332,7 @@ class GraphSampler:
             cfgs = [None] * k["steps"]
         toks = _sample_core(self.model, self.cond, self.uncond, self.shape, None, k["steps"], k["renoise_steps"], t_list, temps, cfgs,
                             self.device, noise="philox", seed=0, attn_weights=self.attn_weights, seed_dev=self.seed_dev,
-                            init_noise_buf=self.init_noise, r_all=self.r_all, ws=self.ws)
+                            init_noise_buf=self.init_noise, r_all=self.r_all, ws=self.ws, row_offset_dev=self.row_offset_dev)
         return toks if self.vqgan is None else (toks, self.vqgan.decode_indices(toks, ws=self.vq_ws))
 
     @staticmethod
@@ -344,17 +359,21 @@ class GraphSampler:
 
     def __call__(self, model_inputs=None, unconditional_inputs=None, seed=None, shard=None):
         """Replay. Returns tokens (and the decoded image if a VQGAN was given); outputs live in graph-owned buffers that
-        the next replay overwrites.  seed=None draws a fresh seed from torch's generator; the start tokens and all per-step
-        noise are functions of the seed (and of the global row when shard=(lo, total) is given)."""
+        the next replay overwrites.  seed=None draws a fresh seed from torch's CPU generator; the start tokens and all per-step
+        noise are functions of the seed and of the GLOBAL row: shard=(lo, total) makes this replay rows [lo, lo + B) of a
+        global batch of `total` (bit-identical to those rows of the unsharded call with the same seed)."""
         if model_inputs is not None:
             self._copy_inputs(self.cond, model_inputs)
         if unconditional_inputs is not None:
             self._copy_inputs(self.uncond, unconditional_inputs)
         if seed is None:
             seed = fresh_seed()
+        lo = 0
         if shard is not None:
-            raise ValueError("a captured graph has its row offset baked in; use sample(..., shard=) for sharded parity runs")
-        self.init_noise.copy_(start_tokens(self.model.num_labels, self.shape, seed, self.device))
+            lo, total = int(shard[0]), int(shard[1])
+            if lo < 0 or lo + self.shape[0] > total:
+                raise ValueError("shard=(lo, total): rows [lo, lo + %d) must lie inside the global batch" % self.shape[0])
+        self.row_offset_dev.fill_(lo * self.shape[1] * self.shape[2])
         self.seed_dev.fill_(int(seed))
         self.graph.replay()
         return self.out
