@@ -31,6 +31,7 @@
 #include "gemm_device.h"
 #include "philox.h"
 #include <stdio.h>
+#include <stdlib.h>
 #include <type_traits>
 #include <vector>
 
@@ -87,13 +88,17 @@ extern "C" int paella_probe_gemm_clock(unsigned long long* out2) {
 }
 #endif
 
-template <int WM, int WN, int TM, int TN, int PD, int APRO, bool TAIL = false, int BK = 32, bool DMA = false>  // BK: K step (32 or 64 floats per LDS row); APRO: 0 none, 1 GRN scale/shift, 2 LayerNorm from row statistics; TAIL: fused sampling tail (head GEMM);
+template <int WM, int WN, int TM, int TN, int PD, int APRO, bool TAIL = false, int BK = 32, bool DMA = false, int RING = 0>  // BK: K step (32 or 64 floats per LDS row); APRO: 0 none, 1 GRN scale/shift, 2 LayerNorm from row statistics; TAIL: fused sampling tail (head GEMM);
 // DMA: operands that need no transform (W always, A when APRO == 0) go global -> LDS directly (buffer_load ... lds), no staging registers, no ds_write pass
+// RING > 0 (the batch-1 kernels): BOTH operands always go global -> LDS directly into a ring of RING stages with RING - 1 units in flight per workgroup
+// (the prefetch depth costs LDS, not registers), and an A-operand prologue is applied to the MFMA FRAGMENTS after they are read back from LDS (GRN scale /
+// shift rows ride along in a 2 KB side stage; LayerNorm mean / rstd live in two registers per fragment row).  One barrier per unit, no ds_write at all.
 // The 32x32 tile is the batch-1 workhorse and wants 5 workgroups per CU (1280 resident): ask for <= 96 VGPRs there.  Not for the
 // GRN-prologue variant (two more staged operands per unit): forced under 96 registers it spills inside the unit loop (measured
 // 33 us instead of 25 for 128x1280x5120), so it runs 4 workgroups per CU and the heuristic gives it at most 1024 workgroups.
 // The 8-wave 128x64 tiles fit 128 VGPRs without spilling when asked to (126 / 128): two workgroups per CU instead of one.
-__global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 && PD == 2 && BK == 32 && APRO != 1) ? 5
+__global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (TM * TN == 1 ? (RING == 3 ? 5 : 4) : (TM * TN == 2 ? 4 : 3))
+                                           : (WM == 2 && WN == 2 && TM * TN == 1 && PD == 2 && BK == 32 && APRO != 1) ? 5
                                            : ((WM * WN == 8 && WM * TM == 8 && WN * TN == 4 && PD == 2 && BK == 32 && APRO == 0 && !TAIL) ? 4 : 1)) void gemm_nt_kernel(GemmArgs g, SkPlan p, float* __restrict__ slabs,
                                                                unsigned* __restrict__ tickets, unsigned slab_bytes) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
@@ -109,12 +114,18 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 &
     // Direct-to-LDS operands: one buffer_load_dwordx4 ... lds per wave and 8 tile rows writes 1 KiB at M0 + lane * 16, i.e. LDS stays
     // lane-linear; the XOR swizzle of the 16-byte slots is applied to the SOURCE address instead (lane l of a row fetches chunk
     // (l % 8) ^ (row % 8)).  Needs K % BK == 0 (no activation-side K-tail mask) -- the host picks the register-staged twin otherwise.
-    constexpr bool DMA_W = DMA, DMA_A = DMA && APRO == 0;
+    constexpr bool DMA_W = DMA || RING > 0, DMA_A = (DMA && APRO == 0) || RING > 0;
     static_assert(!DMA || (PD == 1 && BK == 32 && !TAIL && (BM * SL) % NT == 0 && (BN * SL) % NT == 0), "DMA variant: 1-deep, K step 32, whole passes");
+    static_assert(RING == 0 || (RING >= 3 && RING <= 4 && !DMA && PD == 1 && BK == 32 && !TAIL && APRO != 3 && NW == 4 && (BM * SL) % NT == 0 && (BN * SL) % NT == 0),
+                  "ring variant: 3 or 4 LDS stages, 4 waves, K step 32, whole passes, no implicit convolution");
+    // ring stage = the A and W tiles + (GRN prologue) a 2 KB side stage: 8 copies of shift[k0 .. k0 + 32) | scale rows of 8 consecutive samples
+    constexpr int AUX_FLOATS = (RING > 0 && APRO == 1) ? 512 : 0;
+    constexpr int STAGE_FLOATS = TILE_FLOATS + AUX_FLOATS;
+    constexpr int FLAG_OFF = RING > 0 ? RING * STAGE_FLOATS : 2 * TILE_FLOATS;  // 16 floats for the ticket broadcast behind the stages
     // one LDS object: two tile stages + 16 floats for the ticket broadcast (the NEXT unit's tile is already staged when a
     // segment is flushed, so the flag cannot live inside the stages)
     constexpr int TAIL_FLOATS = TAIL ? BM * WN * 2 : 0;  // fused tail: per row and wave column, the best (score, label)
-    __shared__ __attribute__((aligned(16))) float smem[2 * TILE_FLOATS + 16 + TAIL_FLOATS];
+    __shared__ __attribute__((aligned(16))) float smem[FLAG_OFF + 16 + TAIL_FLOATS];
 
     // ---- this workgroup's unit range ----
     const unsigned G = gridDim.x;
@@ -179,6 +190,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 &
     __amdgpu_buffer_rsrc_t rsrcS = rsrc_of(g.A, 16);
     const __amdgpu_buffer_rsrc_t rsrcT = rsrc_of(APRO == 1 ? g.a_shift : g.A, APRO == 1 ? (size_t)g.K * sizeof(float) : 16);
     unsigned aoff[LA], soff[APRO == 1 ? LA : 1], boff[LB];
+    unsigned aux_s_off = 0;  // ring + GRN prologue: this lane's source offset in the scale rows of the tile's samples (lane -> sample lane / 8, 16-byte chunk lane % 8)
     int cy[APRO == 3 ? LA : 1], cx[APRO == 3 ? LA : 1];  // implicit conv: top-left input coordinate of row i (aoff[i] = image base position)
     int ltap = 0, lc0 = 0;                                  // implicit conv: tap and channel offset of the load cursor's K step
     float ln_mu[APRO == 2 ? LA : 1], ln_rs[APRO == 2 ? LA : 1];
@@ -215,7 +227,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 &
             } else {
                 aoff[i] = ((unsigned)(gmc - m0) * (unsigned)g.lda + (unsigned)((DMA_A ? (ldc4 ^ (ldrow & (SL - 1))) : ldc4) * 4)) * 4u;
             }
-            if (APRO == 1) soff[i] = ((unsigned)(gmc / g.a_rows_per_sample - smp0) * (unsigned)g.K + (unsigned)(ldc4 * 4)) * 4u;
+            if (APRO == 1 && RING == 0) soff[i] = ((unsigned)(gmc / g.a_rows_per_sample - smp0) * (unsigned)g.K + (unsigned)(ldc4 * 4)) * 4u;
+        }
+        if (APRO == 1 && RING > 0) {
+            const int last = (g.M - 1) / g.a_rows_per_sample - smp0;  // clamp: rows past the last sample re-read it (never used)
+            aux_s_off = ((unsigned)min(lane_k >> 3, last) * (unsigned)g.K + (unsigned)((lane_k & 7) * 4)) * 4u;
         }
 #pragma unroll
         for (int i = 0; i < LB; ++i) boff[i] = ((unsigned)(min(n0 + ldrow + i * RP, g.N - 1) - n0) * (unsigned)g.ldw + (unsigned)((DMA_W ? (ldc4 ^ (ldrow & (SL - 1))) : ldc4) * 4)) * 4u;
@@ -225,7 +241,26 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 &
         ltap = (lkt * BK) / g.cv.C;
         lc0 = lkt * BK - ltap * g.cv.C;
     }
-    if (APRO == 2) {
+    float fr_mu[(APRO == 2 && RING > 0) ? TM : 1], fr_rs[(APRO == 2 && RING > 0) ? TM : 1];  // ring: mean / rstd of this lane's fragment rows
+    if (APRO == 2 && RING > 0) {
+        // the 4 lanes that hold one fragment row (kq = 0..3) split the producer's per-16-column (sum, sumsq) blocks and xor-reduce; fp64 as below
+        int ln_tm, ln_tn;
+        sk_tile_coords<(BM >= 64)>(p, ltile, ln_tm, ln_tn);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int gmc = min(ln_tm * BM + (wm * TM + i) * 16 + r16, g.M - 1);
+            const float* stp = g.ln_stats + (size_t)gmc * g.ln_nblk * 2;
+            double sm = 0.0, q = 0.0;
+            for (int j = kq; j < g.ln_nblk; j += 4) { sm += (double)stp[2 * j]; q += (double)stp[2 * j + 1]; }
+            sm += __shfl_xor(sm, 16, 64); q += __shfl_xor(q, 16, 64);
+            sm += __shfl_xor(sm, 32, 64); q += __shfl_xor(q, 32, 64);
+            const double mean = sm / (double)g.K;
+            const double var = q / (double)g.K - mean * mean;
+            fr_mu[i] = (float)mean;
+            fr_rs[i] = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + (double)g.ln_eps));
+        }
+    }
+    if (APRO == 2 && RING == 0) {
         // LayerNorm-on-load: combine the producer's per-16-column (sum, sumsq) partials of this thread's rows; the 8 lanes that
         // share a row (tid & 7) split the blocks and xor-reduce.  fp64 for the final E[x^2] - mean^2.  Computed ONCE: the host
         // only launches this variant with ranges that never change tile_m (tiles_m == 1, or every range inside one tile).
@@ -248,9 +283,21 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 &
     }
 
     auto load_unit = [&](Stage& r, int dma_slot) __attribute__((always_inline)) {  // loads the unit under the load cursor (DMA operands: into LDS stage dma_slot)
-        float* dAs = smem + dma_slot * TILE_FLOATS + (wave * (64 / SL)) * BK;  // this wave's first row group of the stage (wave-uniform -> M0)
+        float* dAs = smem + dma_slot * (RING > 0 ? STAGE_FLOATS : TILE_FLOATS) + (wave * (64 / SL)) * BK;  // this wave's first row group of the stage (wave-uniform -> M0)
         float* dBs = dAs + BM * BK;
         const int kofs = lkt * (BK * 4);  // uniform byte offset of this K step -> the loads' SGPR offset
+        if constexpr (RING > 0) {
+#pragma unroll
+            for (int i = 0; i < LA; ++i) dma_b128_to_lds(rsrcA, dAs + i * RP * BK, aoff[i], kofs);
+#pragma unroll
+            for (int i = 0; i < LB; ++i) dma_b128_to_lds(rsrcW, dBs + i * RP * BK, boff[i], kofs);
+            if (APRO == 1 && wave == NW - 1) {  // the side stage: 1 KB of shift (8 copies of the 128-byte row), 1 KB of scale rows
+                float* dX = smem + dma_slot * STAGE_FLOATS + TILE_FLOATS;
+                dma_b128_to_lds(rsrcT, dX, (unsigned)((lane_k & 7) * 16), kofs);
+                dma_b128_to_lds(rsrcS, dX + 256, aux_s_off, kofs);
+            }
+            return;
+        }
         int oy = 0, ox = 0;
         if (APRO == 3) {
             oy = g.cv.oy0 + g.cv.tsign * (ltap >> g.cv.tw_log2);  // uniform scalar arithmetic
@@ -411,7 +458,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 &
             const uint64_t seed = ft.seed + (ft.seed_ptr ? *ft.seed_ptr : 0ull);
             const int64_t row_off = ft.row_offset + (ft.row_offset_ptr ? *ft.row_offset_ptr : 0);
             const int L4 = g.N >> 2;
-            float* s_score = smem + 2 * TILE_FLOATS + 16;
+            float* s_score = smem + FLAG_OFF + 16;
             int* s_idx = reinterpret_cast<int*>(s_score + BM * WN);
             const int tile_n_id = n0 / BN;
 #pragma unroll
@@ -524,7 +571,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 &
                                                            mybase + ((i * TN + j) * 64 + lane) * 16, 0, 16);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            unsigned* sflag = reinterpret_cast<unsigned*>(smem + 2 * TILE_FLOATS);
+            unsigned* sflag = reinterpret_cast<unsigned*>(smem + FLAG_OFF);
             if (tid == 0) sflag[0] = __hip_atomic_fetch_add(tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
             // the workgroups whose ranges intersect this tile's units [tb, tb + KT)
@@ -566,6 +613,119 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 &
     // ---- the unit stream ----
     // invariant at the top of unit i: unit i is in LDS[slot]; R[(i+1)%PD .. (i+PD-1)%PD] hold units i+1..i+PD-1; R[i%PD] is free
     int loaded = 0;  // units fetched so far; the load cursor stops on the range's last unit (re-reading it hits L1/L2)
+    if constexpr (RING > 0) {
+        // ===== ring variant: RING LDS stages, RING - 1 units in flight, both operands by LDS-DMA, prologue on the fragments =====
+        int sidx[(APRO == 1) ? TM : 1];  // GRN prologue: sample (relative to the tile's first) of this lane's fragment rows
+        auto enter_tile = [&](int tile) __attribute__((always_inline)) {
+            if (APRO != 1) return;
+            int tile_m, tile_n;
+            sk_tile_coords<(BM >= 64)>(p, tile, tile_m, tile_n);
+            const int m0 = tile_m * BM, smp0 = m0 / g.a_rows_per_sample;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) sidx[i] = min(m0 + (wm * TM + i) * 16 + r16, g.M - 1) / g.a_rows_per_sample - smp0;
+        };
+        auto compute_ring = [&](int cs) __attribute__((always_inline)) {
+            const float* As = smem + cs * STAGE_FLOATS;
+            const float* Bs = As + BM * BK;
+            f32x4 af[KG][TM], bf[KG][TN];
+#pragma unroll
+            for (int kk = 0; kk < KG; ++kk) {
+                const int c4 = kk * 4 + kq;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int row = (wm * TM + i) * 16 + r16;
+                    af[kk][i] = *reinterpret_cast<const f32x4*>(As + row * BK + ((c4 ^ (row & (SL - 1))) << 2));
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int row = (wn * TN + j) * 16 + r16;
+                    bf[kk][j] = *reinterpret_cast<const f32x4*>(Bs + row * BK + ((c4 ^ (row & (SL - 1))) << 2));
+                }
+            }
+            if (APRO == 1) {  // GlobalResponseNorm apply on the fragments: a' = a * scale[sample][k] + shift[k] (same expression as the staged form)
+                const float* X = Bs + BN * BK;
+#pragma unroll
+                for (int kk = 0; kk < KG; ++kk) {
+                    const int c4 = kk * 4 + kq;
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(X + c4 * 4);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const f32x4 sc = *reinterpret_cast<const f32x4*>(X + 256 + sidx[i] * 32 + c4 * 4);
+                        af[kk][i] = af[kk][i] * sc + t;
+                    }
+                }
+            }
+            if (APRO == 2) {
+#pragma unroll
+                for (int kk = 0; kk < KG; ++kk)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) af[kk][i] = (af[kk][i] - fr_mu[i]) * fr_rs[i];
+            }
+            if (TM * TN == 1) {
+#pragma unroll
+                for (int kk = 0; kk < KG; kk += 2)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[kk][0][e], af[kk][0][e], acc[0][0], 0, 0, 0);
+                        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[kk + 1][0][e], af[kk + 1][0][e], acc2, 0, 0, 0);
+                    }
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < KG; ++kk)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[kk][j][e], af[kk][i][e], acc[i][j], 0, 0, 0);
+            }
+        };
+        auto fetch_ring = [&](int stage) __attribute__((always_inline)) {
+            load_unit(R[0], stage);
+            if (++loaded < n) {  // the cursor stops on the range's last unit: re-issuing it keeps the per-wave DMA count per unit constant (vmcnt arithmetic)
+                if (++lkt == KT) {
+                    lkt = 0;
+                    ++ltile;
+                    set_tile(ltile);
+                }
+            }
+        };
+        constexpr int PER_UNIT = LA + LB;  // LDS-DMA instructions per unit and wave; the last wave issues 2 more with the GRN side stage
+#pragma unroll
+        for (int j = 0; j < RING - 1; ++j) fetch_ring(j);
+        int cs = 0, ls = RING - 1;
+        int ctile = (int)(u0 / (unsigned)KT);
+        int ckt = (int)(u0 - (unsigned)ctile * (unsigned)KT);
+        bool first_seg = true;
+        for (int i = 0; i < n;) {
+            const int seg_len = min(KT - ckt, n - i);
+            enter_tile(ctile);
+            for (int s2 = 0; s2 < seg_len; ++s2) {
+                // this wave's share of the oldest unit has landed; the barrier then publishes every wave's share -- and guarantees that all
+                // waves are done reading stage `ls` (the unit computed one iteration ago), which the next DMA overwrites
+                if (APRO == 1 && wave == NW - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 2) * (PER_UNIT + 2)) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 2) * PER_UNIT) : "memory");
+                // a bare s_barrier: __syncthreads() carries a workgroup-scope fence, which drains EVERY LDS-DMA in flight (vmcnt(0)) and would
+                // collapse the ring to one unit.  The fragment reads of the previous unit were consumed by its MFMAs, so nothing else is pending.
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                fetch_ring(ls);
+                __builtin_amdgcn_sched_barrier(0);
+                compute_ring(cs);
+                __builtin_amdgcn_sched_barrier(0);
+                cs = cs + 1 == RING ? 0 : cs + 1;
+                ls = ls + 1 == RING ? 0 : ls + 1;
+            }
+            if (i + seg_len == n) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may still be landing when the workgroup's LDS is released
+            flush(ctile, ckt, ckt + seg_len, first_seg);
+            first_seg = false;
+            i += seg_len;
+            ckt += seg_len;
+            if (ckt == KT) { ckt = 0; ++ctile; }
+        }
+        return;
+    }
     auto fetch = [&](Stage& r, int dma_slot) __attribute__((always_inline)) {
         load_unit(r, dma_slot);
         if (++loaded < n) {  // workgroup-uniform; never runs into the next workgroup's units
@@ -663,7 +823,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM == 2 && WN == 2 && TM * TN == 1 &
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
-struct TileCfg { int wm, wn, tm, tn, pd, bk; };
+struct TileCfg { int wm, wn, tm, tn, pd, bk, ring; };
 // BM = wm*tm*16, BN = wn*tn*16; ids are stable (tests and tools name them)
 static const TileCfg kCfgs[] = {
     {2, 2, 4, 4, 1, 32},  // 0: 128x128
@@ -696,6 +856,13 @@ static const TileCfg kCfgs[] = {
     {4, 1, 2, 2, 1, 64},  // 27: 128x32 stacked, K step 64, 1-deep prefetch
     {2, 2, 1, 2, 1, 64},  // 28: 32x64, K step 64, 1-deep prefetch
     {4, 2, 2, 2, 1, 64},  // 29: 128x64, 8 waves, K step 64, 1-deep prefetch
+    // ring variants (both operands by LDS-DMA into 3 / 4 stages, prologues applied to the fragments); need K % 32 == 0
+    {2, 2, 1, 1, 1, 32, 3},  // 30: 32x32, 3 stages (2 units in flight, 5 workgroups per CU)
+    {2, 2, 1, 1, 1, 32, 4},  // 31: 32x32, 4 stages (3 units in flight, 4 workgroups per CU)
+    {2, 2, 1, 2, 1, 32, 3},  // 32: 32x64, 3 stages
+    {2, 2, 2, 1, 1, 32, 3},  // 33: 64x32, 3 stages
+    {2, 2, 2, 2, 1, 32, 3},  // 34: 64x64, 3 stages
+    {2, 2, 1, 2, 1, 32, 4},  // 35: 32x64, 4 stages
 };
 static const int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 int gemm_num_tile_configs() { return kNumCfgs; }
@@ -716,6 +883,16 @@ static int g_gemm_raster_gm = 8;  // tile rows per rasterisation group (0 = plai
 extern "C" int paella_test_gemm_raster(int gm) { g_gemm_raster_gm = gm; return PAELLA_OK; }
 static int g_gemm_dma = 1;  // test hook (test_hooks.h): 0 = always the register-staged kernels
 extern "C" int paella_test_gemm_dma(int on) { g_gemm_dma = on != 0; return PAELLA_OK; }
+
+template <int TM, int TN, int RING>
+static void launch_ring(const GemmArgs& g, const SkPlan& p, unsigned G, float* slabs, unsigned* tickets, unsigned slab_bytes, hipStream_t st) {
+    if (g.a_scale)
+        hipLaunchKernelGGL((gemm_nt_kernel<2, 2, TM, TN, 1, 1, false, 32, false, RING>), dim3(G), dim3(256), 0, st, g, p, slabs, tickets, slab_bytes);
+    else if (g.ln_stats)
+        hipLaunchKernelGGL((gemm_nt_kernel<2, 2, TM, TN, 1, 2, false, 32, false, RING>), dim3(G), dim3(256), 0, st, g, p, slabs, tickets, slab_bytes);
+    else
+        hipLaunchKernelGGL((gemm_nt_kernel<2, 2, TM, TN, 1, 0, false, 32, false, RING>), dim3(G), dim3(256), 0, st, g, p, slabs, tickets, slab_bytes);
+}
 
 template <int WM, int WN, int TM, int TN, int PD, int BK>
 static void launch_one(const GemmArgs& g, const SkPlan& p, unsigned G, float* slabs, unsigned* tickets, unsigned slab_bytes, hipStream_t st) {
@@ -747,6 +924,12 @@ static void launch_one(const GemmArgs& g, const SkPlan& p, unsigned G, float* sl
         hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, PD, 0, false, BK>), dim3(G), dim3(NT), 0, st, g, p, slabs, tickets, slab_bytes);
 }
 
+// ring tiles: both operands by LDS-DMA (whole K steps only), GRN side stage holds the scale rows of at most 8 consecutive samples
+static bool ring_ok(const GemmArgs& g, int BM) {
+    if (g.K % 32 || g.cv.enabled) return false;
+    if (g.a_scale && (BM - 1) / (g.a_rows_per_sample > 0 ? g.a_rows_per_sample : 1) + 2 > 8) return false;
+    return true;
+}
 static inline long tiles_of_cfg(int c, int M, int N) {
     const int BM = kCfgs[c].wm * kCfgs[c].tm * 16, BN = kCfgs[c].wn * kCfgs[c].tn * 16;
     return (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
@@ -765,7 +948,24 @@ static inline long tiles_of_cfg(int c, int M, int N) {
 //  * skinny batch-1 shapes: 32x32 tiles, ~10 K-steps per workgroup, at most 1280 workgroups = 5 per CU, all resident at once
 //    (__launch_bounds__(256, 5) on that instantiation guarantees the registers for it) -- every larger
 //    tile lands within 5 % of it (24-27 us for 128x5120x1280): these launches are bound by ramp + combine, not by the tile.
-static void choose_config(int M, int N, int K, int apro, size_t slab_cap_bytes, int* cfg_out, unsigned* G_out) {
+// ring tile used for the skinny batch-1 shapes (30..35; 0 = the register-staged / 1-deep DMA kernels).  Test hook + PAELLA_GEMM_RING env override.
+static int g_gemm_ring = []() { const char* e = getenv("PAELLA_GEMM_RING"); return e ? atoi(e) : 0; }();
+extern "C" int paella_test_gemm_ring(int cfg) {
+    if (cfg != 0 && (cfg < 30 || cfg >= kNumCfgs)) { paella_set_error("ring tile config must be 0 or 30..%d", kNumCfgs - 1); return PAELLA_ERR_ARG; }
+    g_gemm_ring = cfg;
+    return PAELLA_OK;
+}
+// workgroups of a ring tile that are resident at once (LDS-limited; profiles/r03_gemm_ring_resources.txt)
+static long ring_resident(int cfg, int apro) {
+    switch (cfg) {
+        case 30: return 1280;
+        case 31: return apro == 1 ? 768 : 1024;
+        case 32: case 33: return apro == 1 ? 768 : 1024;
+        default: return apro == 1 ? 512 : 768;  // 34, 35
+    }
+}
+
+static void choose_config(int M, int N, int K, int apro, bool ring_allowed, size_t slab_cap_bytes, int* cfg_out, unsigned* G_out) {
     const long ktiles = (K + 31) / 32;
     const double macs = (double)M * N * K;
     const long T128 = tiles_of_cfg(10, M, N), T64 = tiles_of_cfg(18, M, N), T32 = tiles_of_cfg(5, M, N);
@@ -785,10 +985,16 @@ static void choose_config(int M, int N, int K, int apro, size_t slab_cap_bytes, 
     } else {
         // plain operands from 128 rows up: the 1-deep twin whose operands go global -> LDS directly is 2-5 % ahead (profiles/r02_gemm_dma_sweep.txt)
         cfg = (apro == 0 && M >= 128 && K % 32 == 0) ? 19 : 5;
-        const long U = T32 * ktiles;
+        long resident = apro == 1 ? 1024 : 1280;  // workgroups that fit at once (see the launch bounds above)
+        long Tc = T32;
+        if (g_gemm_ring && ring_allowed) {
+            cfg = g_gemm_ring;
+            resident = ring_resident(cfg, apro);
+            Tc = tiles_of_cfg(cfg, M, N);
+        }
+        const long U = Tc * ktiles;
         G = U / 10;
-        if (G < T32) G = T32;
-        const long resident = apro == 1 ? 1024 : 1280;  // workgroups that fit at once (see the launch bounds above)
+        if (G < Tc) G = Tc;
         if (G > resident) G = resident;
     }
     const long T = tiles_of_cfg(cfg, M, N);
@@ -906,7 +1112,7 @@ static int launch_gemm_cfg_impl(const GemmArgs& g, int cfg, int splitk, void* ws
     const size_t slab_cap = have_ws ? ws_bytes - kGemmTicketBytes : 0;
     unsigned G = 0;
     if (cfg < 0) {
-        choose_config(g.M, g.N, g.K, g.a_scale ? 1 : (g.ln_stats ? 2 : 0), slab_cap, &cfg, &G);
+        choose_config(g.M, g.N, g.K, g.a_scale ? 1 : (g.ln_stats ? 2 : 0), ring_ok(g, 64), slab_cap, &cfg, &G);
         if (g.cv.enabled && !conv_cfg(cfg)) { paella_set_error("internal: heuristic picked tile %d without a convolution variant", cfg); return PAELLA_ERR_STATE; }
     } else {
         if (cfg >= kNumCfgs) { paella_set_error("gemm: bad tile config %d", cfg); return PAELLA_ERR_ARG; }
@@ -916,6 +1122,7 @@ static int launch_gemm_cfg_impl(const GemmArgs& g, int cfg, int splitk, void* ws
     }
     const TileCfg& tc = kCfgs[cfg];
     const int BM = tc.wm * tc.tm * 16, BN = tc.wn * tc.tn * 16;
+    if (tc.ring && !ring_ok(g, BM)) { paella_set_error("gemm: tile config %d (LDS-DMA ring) needs K %% 32 == 0, no implicit convolution and <= 8 samples per tile", cfg); return PAELLA_ERR_ARG; }
     SkPlan p;
     p.tiles_m = (g.M + BM - 1) / BM;
     p.tiles_n = (g.N + BN - 1) / BN;
@@ -985,6 +1192,12 @@ static int launch_gemm_cfg_impl(const GemmArgs& g, int cfg, int splitk, void* ws
         GEMM_CASE64(27, 4, 1, 2, 2, 1)
         GEMM_CASE64(28, 2, 2, 1, 2, 1)
         GEMM_CASE64(29, 4, 2, 2, 2, 1)
+        case 30: launch_ring<1, 1, 3>(g, p, G, slabs, tickets, slab_bytes, st); break;
+        case 31: launch_ring<1, 1, 4>(g, p, G, slabs, tickets, slab_bytes, st); break;
+        case 32: launch_ring<1, 2, 3>(g, p, G, slabs, tickets, slab_bytes, st); break;
+        case 33: launch_ring<2, 1, 3>(g, p, G, slabs, tickets, slab_bytes, st); break;
+        case 34: launch_ring<2, 2, 3>(g, p, G, slabs, tickets, slab_bytes, st); break;
+        case 35: launch_ring<1, 2, 4>(g, p, G, slabs, tickets, slab_bytes, st); break;
         default: paella_set_error("gemm: bad tile config %d", cfg); return PAELLA_ERR_ARG;
     }
 #undef GEMM_CASE

@@ -20,6 +20,8 @@ int paella_test_gemm_prologue(const float* A, const float* W, float* C, int M, i
                               int rows_per_sample, const float* ln_stats, int tile_cfg, int splitk, void* ws, size_t ws_bytes, void* stream);
 /* 0 = never use the direct-to-LDS (DMA) twins of the large GEMM tiles (A/B and parity checks); 1 = default */
 int paella_test_gemm_dma(int on);
+/* the LDS-DMA ring tile (config id 30..35) the launch heuristic uses for the skinny batch-1 shapes; 0 = the register-staged / 1-deep kernels (A/B) */
+int paella_test_gemm_ring(int cfg);
 /* tile rows per rasterisation group of the GEMM (default 8); 0 = plain m-fastest tile order (A/B) */
 int paella_test_gemm_raster(int gm);
 /* Measurement hook (bench.py roofline line): when enabled, EVERY dense-contraction launch (the head GEMM with the fused sampling tail included)

@@ -50,7 +50,7 @@ def test_gemm_heuristic(lib, M, N, K):
     np.testing.assert_allclose(C.cpu().numpy(), ref.numpy(), atol=2e-5 * max(1, K ** 0.5 / 8), rtol=1e-5)
 
 
-N_TILE_CONFIGS = 30  # paella_amd/csrc/gemm.hip kCfgs
+N_TILE_CONFIGS = 36  # paella_amd/csrc/gemm.hip kCfgs (30..35: the LDS-DMA ring tiles of the batch-1 path)
 
 
 @pytest.mark.parametrize("cfg", range(N_TILE_CONFIGS))
@@ -133,7 +133,8 @@ def test_gemm_direct_to_lds_twin_is_bit_identical(lib, cfg, mode, splitk):
     np.testing.assert_allclose(outs[0].cpu().numpy(), (a2 @ W.double().t()).float().numpy(), atol=1e-3, rtol=2e-5)
 
 
-@pytest.mark.parametrize("cfg,G", [(5, 512), (11, 512), (12, 256), (12, 509), (13, 768), (14, 256), (16, 256), (22, 640), (9, 300), (2, 1000), (24, 512), (25, 777), (26, 100), (29, 64)])
+@pytest.mark.parametrize("cfg,G", [(5, 512), (11, 512), (12, 256), (12, 509), (13, 768), (14, 256), (16, 256), (22, 640), (9, 300), (2, 1000), (24, 512), (25, 777), (26, 100), (29, 64),
+                                   (30, 512), (30, 1280), (31, 777), (32, 300), (33, 301), (34, 100), (35, 64)])
 def test_gemm_stream_k_is_repeatable(lib, cfg, G):
     """Balanced unit ranges (partial tiles combined by the last arriver in fixed part order): many back-to-back launches on
     one workspace give bit-identical, correct results -- tickets re-arm, slabs are re-used, no stale reads."""

@@ -81,7 +81,8 @@ def main():
         tile_of = {0: (128, 128), 1: (128, 64), 2: (64, 64), 3: (64, 32), 4: (32, 64), 5: (32, 32), 6: (16, 64), 7: (16, 128), 8: (32, 128),
                    9: (128, 128), 10: (128, 128), 11: (128, 32), 12: (128, 64), 13: (64, 64), 14: (128, 64), 15: (256, 32), 16: (256, 64),
                    17: (128, 64), 18: (64, 64), 19: (32, 32), 20: (128, 64), 21: (64, 32), 22: (32, 128), 23: (32, 64),
-                   24: (32, 32), 25: (32, 32), 26: (64, 64), 27: (128, 32), 28: (32, 64), 29: (128, 64)}
+                   24: (32, 32), 25: (32, 32), 26: (64, 64), 27: (128, 32), 28: (32, 64), 29: (128, 64),
+                   30: (32, 32), 31: (32, 32), 32: (32, 64), 33: (64, 32), 34: (64, 64), 35: (32, 64)}  # 30..35: LDS-DMA ring tiles
         bk_of = {c: (64 if 24 <= c <= 29 else 32) for c in tile_of}
         def fits(c):  # skip tiles that waste more than half their rows on this M
             bm = tile_of[c][0]
