@@ -241,25 +241,8 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (TM * TN == 1 ? (RING == 3
         ltap = (lkt * BK) / g.cv.C;
         lc0 = lkt * BK - ltap * g.cv.C;
     }
-    float fr_mu[(APRO == 2 && RING > 0) ? TM : 1], fr_rs[(APRO == 2 && RING > 0) ? TM : 1];  // ring: mean / rstd of this lane's fragment rows
-    if (APRO == 2 && RING > 0) {
-        // the 4 lanes that hold one fragment row (kq = 0..3) split the producer's per-16-column (sum, sumsq) blocks and xor-reduce; fp64 as below
-        int ln_tm, ln_tn;
-        sk_tile_coords<(BM >= 64)>(p, ltile, ln_tm, ln_tn);
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int gmc = min(ln_tm * BM + (wm * TM + i) * 16 + r16, g.M - 1);
-            const float* stp = g.ln_stats + (size_t)gmc * g.ln_nblk * 2;
-            double sm = 0.0, q = 0.0;
-            for (int j = kq; j < g.ln_nblk; j += 4) { sm += (double)stp[2 * j]; q += (double)stp[2 * j + 1]; }
-            sm += __shfl_xor(sm, 16, 64); q += __shfl_xor(q, 16, 64);
-            sm += __shfl_xor(sm, 32, 64); q += __shfl_xor(q, 32, 64);
-            const double mean = sm / (double)g.K;
-            const double var = q / (double)g.K - mean * mean;
-            fr_mu[i] = (float)mean;
-            fr_rs[i] = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + (double)g.ln_eps));
-        }
-    }
+    float fr_mu[(APRO == 2 && RING > 0) ? TM : 1], fr_rs[(APRO == 2 && RING > 0) ? TM : 1];  // ring: mean / rstd of this lane's fragment rows (set behind the first DMAs)
+    const int ln_tile0 = ltile;
     if (APRO == 2 && RING == 0) {
         // LayerNorm-on-load: combine the producer's per-16-column (sum, sumsq) partials of this thread's rows; the 8 lanes that
         // share a row (tid & 7) split the blocks and xor-reduce.  fp64 for the final E[x^2] - mean^2.  Computed ONCE: the host
@@ -694,6 +677,37 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (TM * TN == 1 ? (RING == 3
         constexpr int PER_UNIT = LA + LB;  // LDS-DMA instructions per unit and wave; the last wave issues 2 more with the GRN side stage
 #pragma unroll
         for (int j = 0; j < RING - 1; ++j) fetch_ring(j);
+        if (APRO == 2) {
+            // LayerNorm-on-load statistics, computed while the first units are in flight: the 4 lanes that hold one fragment row (kq = 0..3)
+            // split the producer's per-16-column (sum, sumsq) pairs as 16-byte chunks (two blocks each) and xor-reduce; fp64 for E[x^2] - mean^2.
+            // Computed ONCE: the host only launches this variant with ranges that never change tile_m.
+            int ln_tm, ln_tn;
+            sk_tile_coords<(BM >= 64)>(p, ln_tile0, ln_tm, ln_tn);
+            const int nch = g.ln_nblk >> 1;  // 16-byte chunks per row (K % 32 == 0 -> ln_nblk even)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int gmc = min(ln_tm * BM + (wm * TM + i) * 16 + r16, g.M - 1);
+                const f32x4* stp = reinterpret_cast<const f32x4*>(g.ln_stats + (size_t)gmc * g.ln_nblk * 2);
+                double sm = 0.0, q = 0.0;
+                int j = kq;
+                for (; j + 12 < nch; j += 16) {  // 4 independent loads in flight
+                    const f32x4 v0 = stp[j], v1 = stp[j + 4], v2 = stp[j + 8], v3 = stp[j + 12];
+                    sm += ((double)v0[0] + (double)v0[2]) + ((double)v1[0] + (double)v1[2]) + ((double)v2[0] + (double)v2[2]) + ((double)v3[0] + (double)v3[2]);
+                    q += ((double)v0[1] + (double)v0[3]) + ((double)v1[1] + (double)v1[3]) + ((double)v2[1] + (double)v2[3]) + ((double)v3[1] + (double)v3[3]);
+                }
+                for (; j < nch; j += 4) {
+                    const f32x4 v0 = stp[j];
+                    sm += (double)v0[0] + (double)v0[2];
+                    q += (double)v0[1] + (double)v0[3];
+                }
+                sm += __shfl_xor(sm, 16, 64); q += __shfl_xor(q, 16, 64);
+                sm += __shfl_xor(sm, 32, 64); q += __shfl_xor(q, 32, 64);
+                const double mean = sm / (double)g.K;
+                const double var = q / (double)g.K - mean * mean;
+                fr_mu[i] = (float)mean;
+                fr_rs[i] = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + (double)g.ln_eps));
+            }
+        }
         int cs = 0, ls = RING - 1;
         int ctile = (int)(u0 / (unsigned)KT);
         int ckt = (int)(u0 - (unsigned)ctile * (unsigned)KT);
@@ -948,8 +962,9 @@ static inline long tiles_of_cfg(int c, int M, int N) {
 //  * skinny batch-1 shapes: 32x32 tiles, ~10 K-steps per workgroup, at most 1280 workgroups = 5 per CU, all resident at once
 //    (__launch_bounds__(256, 5) on that instantiation guarantees the registers for it) -- every larger
 //    tile lands within 5 % of it (24-27 us for 128x5120x1280): these launches are bound by ramp + combine, not by the tile.
-// ring tile used for the skinny batch-1 shapes (30..35; 0 = the register-staged / 1-deep DMA kernels).  Test hook + PAELLA_GEMM_RING env override.
-static int g_gemm_ring = []() { const char* e = getenv("PAELLA_GEMM_RING"); return e ? atoi(e) : 0; }();
+// ring tile used for the skinny batch-1 shapes (30..35; 0 = the register-staged / 1-deep DMA kernels of round 2, kept for A/B).  Default 30 (32x32,
+// 3 stages; the LayerNorm-prologue GEMMs take its 4-stage sibling 31).  Test hook + PAELLA_GEMM_RING env override.
+static int g_gemm_ring = []() { const char* e = getenv("PAELLA_GEMM_RING"); return e ? atoi(e) : 30; }();
 extern "C" int paella_test_gemm_ring(int cfg) {
     if (cfg != 0 && (cfg < 30 || cfg >= kNumCfgs)) { paella_set_error("ring tile config must be 0 or 30..%d", kNumCfgs - 1); return PAELLA_ERR_ARG; }
     g_gemm_ring = cfg;
@@ -979,6 +994,12 @@ static void choose_config(int M, int N, int K, int apro, bool ring_allowed, size
     } else if (macs >= 2.5e9) {
         if (K <= 768 && T64 >= 1024) { cfg = 18; G = T64; }
         else { cfg = 10; G = 256; }
+    } else if (g_gemm_ring && ring_allowed && macs < 2.4e9 && T64 < 1024 && apro != 2) {
+        // 1.2-2.4 GFLOP with few tiles (256x5120x1280, 1024x1280x1280, ...): the 32x32 ring tile on every resident slot is 8-12 % ahead of 64x64 tiles
+        cfg = g_gemm_ring;
+        G = ring_resident(cfg, apro);
+        const long Tc = tiles_of_cfg(cfg, M, N);
+        if (G < Tc) G = Tc;
     } else if (macs >= 1.2e9 || T64 >= 1024) {
         cfg = 18;
         G = (T64 >= 2048 || ktiles < 16) ? T64 : 512;  // short K: ranges would be mostly partial tiles
@@ -986,16 +1007,30 @@ static void choose_config(int M, int N, int K, int apro, bool ring_allowed, size
         // plain operands from 128 rows up: the 1-deep twin whose operands go global -> LDS directly is 2-5 % ahead (profiles/r02_gemm_dma_sweep.txt)
         cfg = (apro == 0 && M >= 128 && K % 32 == 0) ? 19 : 5;
         long resident = apro == 1 ? 1024 : 1280;  // workgroups that fit at once (see the launch bounds above)
-        long Tc = T32;
         if (g_gemm_ring && ring_allowed) {
-            cfg = g_gemm_ring;
+            // LDS-DMA ring tiles (profiles/r03_gemm_ring_sweep.txt): 5-15 % ahead of the register-staged / 1-deep tiles on every batch-1 shape.
+            // Every launch carries ~6-7 us of fixed latency (boundary, first fetch, publish / ticket / combine, epilogue round trips) on top of a
+            // K loop that runs at ~130 TFLOP/s, so the workgroup count is fitted to the sweep rather than to "fill the chip":
+            //  * >= 20000 units (the MLP GEMMs at 128 / 512 rows): every resident slot (1280);
+            //  * fewer: ~12 units per workgroup, at most 768 workgroups; >= 512 tiles: one tile per workgroup (no combine at all);
+            //  * LayerNorm prologue: every workgroup re-derives its rows' statistics from the producer's partials, which costs more than the
+            //    split saves -- one tile per workgroup from 160 tiles up (128x3840x1280: 21.0 us against 25.2 with a 2-way split), 2-way below.
+            cfg = (g_gemm_ring == 30 && apro == 2) ? 31 : g_gemm_ring;
             resident = ring_resident(cfg, apro);
-            Tc = tiles_of_cfg(cfg, M, N);
+            const long Tc = tiles_of_cfg(cfg, M, N);
+            const long U = Tc * ktiles;
+            if (apro == 2) G = Tc >= 160 ? Tc : 2 * Tc;
+            else if (U >= 20000) G = resident;
+            else if (Tc >= 512) G = Tc;
+            else { G = U / 12; if (G > 768) G = 768; }
+            if (G < Tc) G = Tc;
+            if (G > resident) G = resident;
+        } else {
+            const long U = T32 * ktiles;
+            G = U / 10;
+            if (G < T32) G = T32;
+            if (G > resident) G = resident;
         }
-        const long U = Tc * ktiles;
-        G = U / 10;
-        if (G < Tc) G = Tc;
-        if (G > resident) G = resident;
     }
     const long T = tiles_of_cfg(cfg, M, N);
     const long U = T * ktiles;

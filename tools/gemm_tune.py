@@ -53,6 +53,8 @@ def main():
     ap.add_argument("--only", default=None, help="substring filter on the shape name (comma-separated alternatives)")
     ap.add_argument("--apro", type=int, default=0, choices=[0, 1, 2], help="A-operand prologue: 0 none, 1 GRN scale/shift (rows per sample = 64), 2 LayerNorm from row statistics")
     ap.add_argument("--raster", type=int, default=None, help="tile rows per rasterisation group (test hook; 0 = plain m-fastest order)")
+    ap.add_argument("--copies", type=int, default=0, help="rotate over exactly this many weight copies (2-3 = the weights stay in the 256 MiB Infinity Cache: "
+                    "the upper bound of what a weight prefetch could buy); default: enough copies to exceed it (cold weights, as in the model)")
     ap.add_argument("--cfgs", default=None, help="comma-separated tile configs to sweep (default: all that fit)")
     a = ap.parse_args()
     lib = _lib.load()
@@ -68,6 +70,8 @@ def main():
         # exactly like consecutive layers of the model; activations stay warm.  One event pair brackets a whole
         # rotation of back-to-back launches, so the figure includes the real launch boundaries.
         ncopy = max(2, min(64, int(600e6 // (N * K * 4)) + 1)) if M < 4096 else 3
+        if a.copies:
+            ncopy = a.copies
         A = torch.randn(M, K, device="cuda")
         Ws = [torch.randn(N, K, device="cuda") for _ in range(ncopy)]
         C = torch.empty(M, N, device="cuda")
@@ -135,6 +139,10 @@ def main():
         print("%-28s best %-8s %8.1f us %6.1f TF | heuristic %8.1f us %6.1f TF | floors hbm %.1f mfma %.1f us | top: %s" %
               (name, r["best"], r["best_us"], r["best_tflops"], heur, r["heuristic_tflops"], r["hbm_floor_us"], r["mfma_floor_us"],
                " ".join("%s=%.1f" % (k, v) for v, k in top)), flush=True)
+        ring = sorted((v, k) for k, v in row.items() if int(k.split("/")[0]) >= 30)[:4]
+        legacy = sorted((v, k) for k, v in row.items() if 0 <= int(k.split("/")[0]) < 30)[:3]
+        if ring and legacy:
+            print("%-28s   ring tiles: %s | register-staged / 1-deep tiles: %s" % ("", " ".join("%s=%.1f" % (k, v) for v, k in ring), " ".join("%s=%.1f" % (k, v) for v, k in legacy)), flush=True)
     if a.out:
         os.makedirs(os.path.dirname(a.out), exist_ok=True)
         json.dump(results, open(a.out, "w"), indent=1)
