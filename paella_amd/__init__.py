@@ -6,8 +6,10 @@ Public surface (mirrors the reference's Python API):
     sample                    reference src/utils.py:35
     sample_distributed        reference src_distributed/utils.py:97
     replace_attention_layers  reference utils/alter_attention.py:45
+    load_conditional_models   reference src_distributed/utils.py:65 (+ embed_prompts, load_checkpoint: paella_amd/conditioning.py)
 Everything executes through libpaella_hip.so (hand-written HIP for gfx950, C ABI in include/paella_hip.h).
 """
+from .conditioning import build_paella, embed_prompts, load_checkpoint, load_conditional_models
 from .editing import inpaint
 from .modules import CondCache, DenoiseUNet, Paella, replace_attention_layers
 from .sampling import GraphSampler, sample, sample_distributed
@@ -30,4 +32,4 @@ def get_gemm_precision():
     return "bf16" if _lib.load().paella_get_gemm_precision() == 1 else "fp32"
 
 __all__ = ["Paella", "DenoiseUNet", "CondCache", "VQModel", "VectorQuantize", "sample", "sample_distributed", "GraphSampler", "set_gemm_precision", "get_gemm_precision",
-           "replace_attention_layers", "inpaint"]
+           "replace_attention_layers", "inpaint", "load_conditional_models", "embed_prompts", "load_checkpoint", "build_paella"]
