@@ -17,6 +17,7 @@
 // load is unconditional from a clamped in-bounds row so the next tile's loads are all in flight while the
 // current tile computes (two register sets, software pipelined; batch-1 sampling is latency-bound here).
 #include "common.h"
+#include <atomic>
 #include <math.h>
 
 // KSPLIT = true : one workgroup per 16 queries, its 4 waves split the key tiles (latency-bound small grids)
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(256) void attention_lds_kernel(AttnArgs args) {
     }
 }
 
-static int g_attn_variant = 0;  // test hook (test_hooks.h): 1 = force the register-fed kernel for large query counts too (A/B probes)
+static std::atomic<int> g_attn_variant{0};  // test hook (test_hooks.h): 1 = force the register-fed kernel for large query counts too (A/B probes)
 extern "C" int paella_test_attention_variant(int v) { g_attn_variant = v; return PAELLA_OK; }
 
 int launch_attention(const AttnArgs& a, hipStream_t st) {

@@ -32,6 +32,8 @@
 #include "philox.h"
 #include <stdio.h>
 #include <stdlib.h>
+#include <atomic>
+#include <mutex>
 #include <type_traits>
 #include <vector>
 
@@ -98,6 +100,7 @@ template <int WM, int WN, int TM, int TN, int PD, int APRO, bool TAIL = false, i
 // 33 us instead of 25 for 128x1280x5120), so it runs 4 workgroups per CU and the heuristic gives it at most 1024 workgroups.
 // The 8-wave 128x64 tiles fit 128 VGPRs without spilling when asked to (126 / 128): two workgroups per CU instead of one.
 __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (TM * TN == 1 ? (RING == 3 ? 5 : 4) : (TM * TN == 2 ? 4 : 3))
+                                           : (TAIL && WM * WN == 8 && TM * TN == 4) ? 4  // fused head + tail on 128x64 tiles: TWO+ workgroups per CU, one's Philox / log epilogue overlaps another's main loop
                                            : (WM == 2 && WN == 2 && TM * TN == 1 && PD == 2 && BK == 32 && APRO != 1) ? 5
                                            : ((WM * WN == 8 && WM * TM == 8 && WN * TN == 4 && PD == 2 && BK == 32 && APRO == 0 && !TAIL) ? 4 : 1)) void gemm_nt_kernel(GemmArgs g, SkPlan p, float* __restrict__ slabs,
                                                                unsigned* __restrict__ tickets, unsigned slab_bytes) {
@@ -893,9 +896,9 @@ template <int WM, int WN, int TM, int TN, int PD, int BK>
 static constexpr bool dma_tile() {
     return BK == 32 && PD == 1 && ((WM == 2 && WN == 4 && TM == 4 && TN == 2) || (WM == 2 && WN == 2 && TM == 2 && TN == 2) || (WM == 2 && WN == 2 && TM == 1 && TN == 1));
 }
-static int g_gemm_raster_gm = 8;  // tile rows per rasterisation group (0 = plain m-fastest); test hook
+static std::atomic<int> g_gemm_raster_gm{8};  // tile rows per rasterisation group (0 = plain m-fastest); test hook
 extern "C" int paella_test_gemm_raster(int gm) { g_gemm_raster_gm = gm; return PAELLA_OK; }
-static int g_gemm_dma = 1;  // test hook (test_hooks.h): 0 = always the register-staged kernels
+static std::atomic<int> g_gemm_dma{1};  // test hook (test_hooks.h): 0 = always the register-staged kernels
 extern "C" int paella_test_gemm_dma(int on) { g_gemm_dma = on != 0; return PAELLA_OK; }
 
 template <int TM, int TN, int RING>
@@ -964,7 +967,7 @@ static inline long tiles_of_cfg(int c, int M, int N) {
 //    tile lands within 5 % of it (24-27 us for 128x5120x1280): these launches are bound by ramp + combine, not by the tile.
 // ring tile used for the skinny batch-1 shapes (30..35; 0 = the register-staged / 1-deep DMA kernels of round 2, kept for A/B).  Default 30 (32x32,
 // 3 stages; the LayerNorm-prologue GEMMs take its 4-stage sibling 31).  Test hook + PAELLA_GEMM_RING env override.
-static int g_gemm_ring = []() { const char* e = getenv("PAELLA_GEMM_RING"); return e ? atoi(e) : 30; }();
+static std::atomic<int> g_gemm_ring{[]() { const char* e = getenv("PAELLA_GEMM_RING"); return e ? atoi(e) : 30; }()};
 extern "C" int paella_test_gemm_ring(int cfg) {
     if (cfg != 0 && (cfg < 30 || cfg >= kNumCfgs)) { paella_set_error("ring tile config must be 0 or 30..%d", kNumCfgs - 1); return PAELLA_ERR_ARG; }
     g_gemm_ring = cfg;
@@ -981,6 +984,7 @@ static long ring_resident(int cfg, int apro) {
 }
 
 static void choose_config(int M, int N, int K, int apro, bool ring_allowed, size_t slab_cap_bytes, int* cfg_out, unsigned* G_out) {
+    const int g_gemm_ring = ::g_gemm_ring.load(std::memory_order_relaxed);  // one consistent value per decision
     const long ktiles = (K + 31) / 32;
     const double macs = (double)M * N * K;
     const long T128 = tiles_of_cfg(10, M, N), T64 = tiles_of_cfg(18, M, N), T32 = tiles_of_cfg(5, M, N);
@@ -1057,6 +1061,7 @@ struct GemmProf {
     std::vector<double> flops, bytes;
 };
 static GemmProf g_prof;
+static std::mutex g_prof_mu;  // enable / record / collect may come from different host threads (one per device in a multi-GPU process)
 
 static int launch_gemm_cfg_impl(const GemmArgs& g, int cfg, int splitk, void* ws, size_t ws_bytes, hipStream_t st);
 
@@ -1064,6 +1069,7 @@ static int launch_gemm_cfg_impl(const GemmArgs& g, int cfg, int splitk, void* ws
 template <typename F>
 static int prof_bracket(const GemmArgs& g, hipStream_t st, bool stores_c, F&& launch) {
     if (!g_prof.on) return launch();
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     if (g_prof.used + 2 > g_prof.pool.size()) {
         for (int i = 0; i < 2; ++i) {
             hipEvent_t e;
@@ -1086,6 +1092,7 @@ int launch_gemm_cfg(const GemmArgs& g, int cfg, int splitk, void* ws, size_t ws_
 }
 
 extern "C" int paella_prof_enable(int on) {
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     g_prof.on = on != 0;
     g_prof.used = 0;
     g_prof.flops.clear();
@@ -1095,6 +1102,7 @@ extern "C" int paella_prof_enable(int on) {
 
 // Sums the event-timed GEMM launches recorded since paella_prof_enable(1) (synchronises on the recorded events).
 extern "C" int paella_prof_collect(double* total_ms, double* total_flops, double* total_bytes, int64_t* launches) {
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     double ms = 0, fl = 0, by = 0;
     const size_t n = g_prof.used / 2;
     for (size_t i = 0; i < n; ++i) {
@@ -1189,7 +1197,8 @@ static int launch_gemm_cfg_impl(const GemmArgs& g, int cfg, int splitk, void* ws
     // grouped rasterisation for launches with many tile rows and columns (test hook: paella_test_gemm_raster)
     // (32-row tiles and skinny problems keep the plain order: their traffic is the weight panel, which m-fastest tiles share best --
     // measured +2 % per image at batch 1 with groups there)
-    p.gm = (g_gemm_raster_gm > 0 && BM >= 64 && p.tiles_m >= 4 * g_gemm_raster_gm && p.tiles_n >= 4) ? g_gemm_raster_gm : p.tiles_m;
+    const int raster_gm = g_gemm_raster_gm;
+    p.gm = (raster_gm > 0 && BM >= 64 && p.tiles_m >= 4 * raster_gm && p.tiles_n >= 4) ? raster_gm : p.tiles_m;
     unsigned* tickets = have_ws ? reinterpret_cast<unsigned*>(ws) : nullptr;
     float* slabs = have_ws ? reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + kGemmTicketBytes) : nullptr;
 #define GEMM_CASE(id, WMv, WNv, TMv, TNv, PDv) \
@@ -1244,7 +1253,15 @@ static int launch_gemm_cfg_impl(const GemmArgs& g, int cfg, int splitk, void* ws
 // ---------------------------------------------------------------------------
 // head GEMM with the fused sampling tail: one whole tile per workgroup (G = tiles), TAIL instantiations only
 // ---------------------------------------------------------------------------
-int gemm_tail_config(int M, int N) { return tiles_of_cfg(9, M, N) >= 256 ? 9 : 2; }
+// tile of the fused head + tail: 9 = 128x128 (one workgroup per CU: the Philox / log epilogue serialises behind the main loop), 14 = 128x64 8 waves
+// (two or more workgroups per CU overlap epilogue and main loop; twice the per-row partials).  Test hook + PAELLA_GEMM_TAIL_TILE env override for A/B.
+static std::atomic<int> g_tail_tile{[]() { const char* e = getenv("PAELLA_GEMM_TAIL_TILE"); return e ? atoi(e) : 9; }()};
+extern "C" int paella_test_gemm_tail_tile(int cfg) {
+    if (cfg != 9 && cfg != 14) { paella_set_error("fused-tail tile must be 9 (128x128) or 14 (128x64)"); return PAELLA_ERR_ARG; }
+    g_tail_tile = cfg;
+    return PAELLA_OK;
+}
+int gemm_tail_config(int M, int N) { return tiles_of_cfg(9, M, N) >= 256 ? g_tail_tile.load() : 2; }
 int gemm_tail_tiles_n(int M, int N) {
     const TileCfg& tc = kCfgs[gemm_tail_config(M, N)];
     const int BN = tc.wn * tc.tn * 16;
@@ -1274,6 +1291,7 @@ static int launch_gemm_tail_impl(const GemmArgs& g, hipStream_t st) {
     p.r = 0;
     p.gm = p.tiles_m;
     if (cfg == 9) hipLaunchKernelGGL((gemm_nt_kernel<4, 2, 2, 4, 1, 0, true>), dim3((unsigned)T), dim3(512), 0, st, g, p, (float*)nullptr, (unsigned*)nullptr, 0u);
+    else if (cfg == 14) hipLaunchKernelGGL((gemm_nt_kernel<4, 2, 2, 2, 2, 0, true>), dim3((unsigned)T), dim3(512), 0, st, g, p, (float*)nullptr, (unsigned*)nullptr, 0u);
     else hipLaunchKernelGGL((gemm_nt_kernel<2, 2, 2, 2, 2, 0, true>), dim3((unsigned)T), dim3(256), 0, st, g, p, (float*)nullptr, (unsigned*)nullptr, 0u);
     LAUNCH_CHECK_RET();
     return PAELLA_OK;

@@ -10,6 +10,8 @@
 // Nothing selects this kernel unless the host called paella_set_gemm_precision(1); the argmax-flip rate against the
 // fp32 path is reported by tests/test_gpu_fastmode.py and bench.py --gemm bf16.
 #include "common.h"
+#include <atomic>
+#include <mutex>
 #include "gemm_device.h"
 #include <map>
 
@@ -245,7 +247,8 @@ __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restric
 
 struct ShadowEntry { size_t numel; unsigned short* b; bool dirty; };
 static std::map<const float*, ShadowEntry> g_shadow;  // keyed by the fp32 tensor's base address
-static int g_precision = 0;                            // 0 = exact fp32 (default), 1 = bf16 operands
+static std::mutex g_shadow_mu;                       // models on different devices / host threads register and look up concurrently
+static std::atomic<int> g_precision{0};                            // 0 = exact fp32 (default), 1 = bf16 operands
 
 // `st` = the stream the fp32 tensor was (re)written on; the copy is complete when this returns
 static int shadow_convert(const float* base, ShadowEntry& e, hipStream_t st) {
@@ -262,6 +265,7 @@ static int shadow_convert(const float* base, ShadowEntry& e, hipStream_t st) {
 // Models call this for every library-owned weight tensor at finalize (and again after a reload: the copy is refreshed).
 int gemm_register_weight(const float* base, size_t numel, hipStream_t st) {
     if (!base || numel == 0) return PAELLA_OK;
+    std::lock_guard<std::mutex> lock(g_shadow_mu);
     ShadowEntry& e = g_shadow[base];
     if (e.b && e.numel != numel) { (void)hipFree(e.b); e.b = nullptr; }
     e.numel = numel;
@@ -270,6 +274,7 @@ int gemm_register_weight(const float* base, size_t numel, hipStream_t st) {
 }
 
 void gemm_unregister_weight(const float* base) {
+    std::lock_guard<std::mutex> lock(g_shadow_mu);
     auto it = g_shadow.find(base);
     if (it == g_shadow.end()) return;
     if (it->second.b) (void)hipFree(it->second.b);
@@ -282,6 +287,7 @@ extern "C" int paella_set_gemm_precision(int mode) {
     if (mode != 0 && mode != 1) { paella_set_error("gemm precision mode must be 0 (fp32) or 1 (bf16 operands)"); return PAELLA_ERR_ARG; }
     if (mode == 1) {
         HIP_CHECK_RET(hipDeviceSynchronize());  // weights may still be in flight on any stream
+        std::lock_guard<std::mutex> lock(g_shadow_mu);
         for (auto& kv : g_shadow)
             if (kv.second.dirty || !kv.second.b) { const int rc = shadow_convert(kv.first, kv.second, 0); if (rc != PAELLA_OK) return rc; }
     }
@@ -293,6 +299,7 @@ extern "C" int paella_get_gemm_precision(void) { return g_precision; }
 
 // bf16 view of an fp32 weight pointer (any offset into a registered tensor), or null
 static const unsigned short* shadow_lookup(const float* W) {
+    std::lock_guard<std::mutex> lock(g_shadow_mu);
     auto it = g_shadow.upper_bound(W);
     if (it == g_shadow.begin()) return nullptr;
     --it;

@@ -22,6 +22,8 @@ int paella_test_gemm_prologue(const float* A, const float* W, float* C, int M, i
 int paella_test_gemm_dma(int on);
 /* the LDS-DMA ring tile (config id 30..35) the launch heuristic uses for the skinny batch-1 shapes; 0 = the register-staged / 1-deep kernels (A/B) */
 int paella_test_gemm_ring(int cfg);
+/* tile of the fused head GEMM + sampling tail: 9 = 128x128 (default), 14 = 128x64 with several workgroups per CU (A/B) */
+int paella_test_gemm_tail_tile(int cfg);
 /* tile rows per rasterisation group of the GEMM (default 8); 0 = plain m-fastest tile order (A/B) */
 int paella_test_gemm_raster(int gm);
 /* Measurement hook (bench.py roofline line): when enabled, EVERY dense-contraction launch (the head GEMM with the fused sampling tail included)
