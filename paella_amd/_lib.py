@@ -91,6 +91,7 @@ SIGNATURES = {
 
 # exported for tests / tools only; declared in paella_amd/csrc/test_hooks.h, not in the public header
 TEST_HOOKS = {
+    "paella_prof_detail": (c_int64, [c_void_p, c_void_p, c_int64]),
     "paella_prof_enable": (c_int, [c_int]),
     "paella_prof_collect": (c_int, [POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int64)]),
     "paella_test_register_weight": (c_int, [c_void_p, c_size_t, c_int]),

@@ -998,7 +998,7 @@ static void choose_config(int M, int N, int K, int apro, bool ring_allowed, size
     } else if (macs >= 2.5e9) {
         if (K <= 768 && T64 >= 1024) { cfg = 18; G = T64; }
         else { cfg = 10; G = 256; }
-    } else if (g_gemm_ring && ring_allowed && macs < 2.4e9 && T64 < 1024 && apro != 2) {
+    } else if (g_gemm_ring && ring_allowed && macs >= 1.2e9 && macs < 2.4e9 && T64 < 1024 && apro != 2) {
         // 1.2-2.4 GFLOP with few tiles (256x5120x1280, 1024x1280x1280, ...): the 32x32 ring tile on every resident slot is 8-12 % ahead of 64x64 tiles
         cfg = g_gemm_ring;
         G = ring_resident(cfg, apro);
@@ -1012,21 +1012,19 @@ static void choose_config(int M, int N, int K, int apro, bool ring_allowed, size
         cfg = (apro == 0 && M >= 128 && K % 32 == 0) ? 19 : 5;
         long resident = apro == 1 ? 1024 : 1280;  // workgroups that fit at once (see the launch bounds above)
         if (g_gemm_ring && ring_allowed) {
-            // LDS-DMA ring tiles (profiles/r03_gemm_ring_sweep.txt): 5-15 % ahead of the register-staged / 1-deep tiles on every batch-1 shape.
-            // Every launch carries ~6-7 us of fixed latency (boundary, first fetch, publish / ticket / combine, epilogue round trips) on top of a
-            // K loop that runs at ~130 TFLOP/s, so the workgroup count is fitted to the sweep rather than to "fill the chip":
-            //  * >= 20000 units (the MLP GEMMs at 128 / 512 rows): every resident slot (1280);
-            //  * fewer: ~12 units per workgroup, at most 768 workgroups; >= 512 tiles: one tile per workgroup (no combine at all);
-            //  * LayerNorm prologue: every workgroup re-derives its rows' statistics from the producer's partials, which costs more than the
-            //    split saves -- one tile per workgroup from 160 tiles up (128x3840x1280: 21.0 us against 25.2 with a 2-way split), 2-way below.
+            // LDS-DMA ring tiles: 5-15 % ahead of the register-staged / 1-deep tiles on every batch-1 shape in isolation (profiles/r03_gemm_ring_sweep.txt)
+            // and 5.4 % per image in the model.  Every launch carries ~6-7 us of fixed latency (boundary, first fetch, publish / ticket / combine,
+            // epilogue round trips) on top of a K loop that runs at ~130 TFLOP/s.  The workgroup count was fitted IN THE MODEL (profiles/r03_ring_rules_ab.txt:
+            // isolated launches with L2-warm activations preferred fewer workgroups and did not predict the model):
+            //  * ~10 K-steps per workgroup, up to every resident slot (1280);
+            //  * LayerNorm prologue: every workgroup re-derives its rows' statistics from the producer's partials, which costs more than a K split
+            //    saves -- one tile per workgroup from 160 tiles up (128x3840x1280: 21.0 us against 25.2 with a 2-way split), 2-way below; 4-stage tile.
             cfg = (g_gemm_ring == 30 && apro == 2) ? 31 : g_gemm_ring;
             resident = ring_resident(cfg, apro);
             const long Tc = tiles_of_cfg(cfg, M, N);
             const long U = Tc * ktiles;
             if (apro == 2) G = Tc >= 160 ? Tc : 2 * Tc;
-            else if (U >= 20000) G = resident;
-            else if (Tc >= 512) G = Tc;
-            else { G = U / 12; if (G > 768) G = 768; }
+            else G = U / 10;
             if (G < Tc) G = Tc;
             if (G > resident) G = resident;
         } else {
@@ -1059,6 +1057,7 @@ struct GemmProf {
     std::vector<hipEvent_t> pool;   // events, used pairwise
     size_t used = 0;
     std::vector<double> flops, bytes;
+    std::vector<int> shape;         // per launch: M, N, K, prologue (0 none, 1 GRN, 2 LayerNorm, 3 implicit conv), tail
 };
 static GemmProf g_prof;
 static std::mutex g_prof_mu;  // enable / record / collect may come from different host threads (one per device in a multi-GPU process)
@@ -1084,6 +1083,8 @@ static int prof_bracket(const GemmArgs& g, hipStream_t st, bool stores_c, F&& la
     g_prof.used += 2;
     g_prof.flops.push_back(2.0 * g.M * g.N * g.K);
     g_prof.bytes.push_back(4.0 * ((double)g.M * g.K + (double)g.N * g.K + (stores_c ? (double)g.M * g.N : 0.0)));
+    const int shp[5] = {g.M, g.N, g.K, g.cv.enabled ? 3 : (g.a_scale ? 1 : (g.ln_stats ? 2 : 0)), stores_c ? 0 : 1};
+    g_prof.shape.insert(g_prof.shape.end(), shp, shp + 5);
     return rc;
 }
 
@@ -1097,7 +1098,23 @@ extern "C" int paella_prof_enable(int on) {
     g_prof.used = 0;
     g_prof.flops.clear();
     g_prof.bytes.clear();
+    g_prof.shape.clear();
     return PAELLA_OK;
+}
+
+// Per-launch records since paella_prof_enable(1), WITHOUT resetting them (call before paella_prof_collect): us_out[i] = duration of launch i,
+// shape_out[5 i ..] = M, N, K, prologue, fused-tail flag.  Returns the number of launches (at most cap are written).
+extern "C" long long paella_prof_detail(float* us_out, int* shape_out, long long cap) {
+    std::lock_guard<std::mutex> lock(g_prof_mu);
+    const size_t n = g_prof.used / 2;
+    for (size_t i = 0; i < n && (long long)i < cap; ++i) {
+        if (hipEventSynchronize(g_prof.pool[2 * i + 1]) != hipSuccess) return -1;
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, g_prof.pool[2 * i], g_prof.pool[2 * i + 1]) != hipSuccess) return -1;
+        us_out[i] = t * 1e3f;
+        for (int k = 0; k < 5; ++k) shape_out[5 * i + k] = g_prof.shape[5 * i + k];
+    }
+    return (long long)n;
 }
 
 // Sums the event-timed GEMM launches recorded since paella_prof_enable(1) (synchronises on the recorded events).
@@ -1118,6 +1135,7 @@ extern "C" int paella_prof_collect(double* total_ms, double* total_flops, double
     g_prof.used = 0;
     g_prof.flops.clear();
     g_prof.bytes.clear();
+    g_prof.shape.clear();
     return PAELLA_OK;
 }
 
@@ -1255,7 +1273,7 @@ static int launch_gemm_cfg_impl(const GemmArgs& g, int cfg, int splitk, void* ws
 // ---------------------------------------------------------------------------
 // tile of the fused head + tail: 9 = 128x128 (one workgroup per CU: the Philox / log epilogue serialises behind the main loop), 14 = 128x64 8 waves
 // (two or more workgroups per CU overlap epilogue and main loop; twice the per-row partials).  Test hook + PAELLA_GEMM_TAIL_TILE env override for A/B.
-static std::atomic<int> g_tail_tile{[]() { const char* e = getenv("PAELLA_GEMM_TAIL_TILE"); return e ? atoi(e) : 9; }()};
+static std::atomic<int> g_tail_tile{[]() { const char* e = getenv("PAELLA_GEMM_TAIL_TILE"); return e ? atoi(e) : 14; }()};
 extern "C" int paella_test_gemm_tail_tile(int cfg) {
     if (cfg != 9 && cfg != 14) { paella_set_error("fused-tail tile must be 9 (128x128) or 14 (128x64)"); return PAELLA_ERR_ARG; }
     g_tail_tile = cfg;

@@ -72,6 +72,11 @@ struct paella_unet {
     std::map<std::string, TensorSpec> specs;
     std::map<std::string, DevBuf> t;
     DevBuf ts_w, ts_b, freqs;
+    // conditioning K|V of EVERY AttnBlock as one GEMM: kv_w [kv_total, c_cond] = rows of in_proj_weight[c:3c] . kv_mapper.1.weight per block
+    // (composed at finalize), kv_b = in_proj_weight[c:3c] . kv_mapper.1.bias + in_proj_bias[c:3c]; kv_col[i] = first column of block i
+    DevBuf kv_w, kv_b;
+    std::vector<int> kv_col;
+    int kv_total = 0;
     int ts_total = 0;
     int n_attn = 0;
     std::vector<int> attn_c;      // channel width per attention block (execution order)
@@ -264,6 +269,8 @@ extern "C" int paella_unet_create(const paella_unet_config* cfg, paella_unet** o
 extern "C" void paella_unet_destroy(paella_unet* m) {
     if (!m) return;
     for (auto& kv : m->t) if (kv.second.p) { gemm_unregister_weight(kv.second.p); (void)hipFree(kv.second.p); }
+    if (m->kv_w.p) { gemm_unregister_weight(m->kv_w.p); (void)hipFree(m->kv_w.p); }
+    if (m->kv_b.p) (void)hipFree(m->kv_b.p);
     if (m->ts_w.p) (void)hipFree(m->ts_w.p);
     if (m->ts_b.p) (void)hipFree(m->ts_b.p);
     if (m->freqs.p) (void)hipFree(m->freqs.p);
@@ -373,6 +380,50 @@ extern "C" int paella_unet_finalize(paella_unet* m, void* stream) {
         auto it = m->t.find(kv.first);
         if (it == m->t.end() || !it->second.loaded) { paella_set_error("tensor '%s' was never loaded", kv.first.c_str()); return PAELLA_ERR_STATE; }
     }
+    // Compose the conditioning projections (reference src/modules.py:72-77: kv = kv_mapper(c_embed), then nn.MultiheadAttention's K / V in-projection
+    // of those rows): K|V = (silu(c) . Wkv^T + bkv) . Win[c:3c]^T + bin[c:3c] = silu(c) . (Win[c:3c] . Wkv)^T + (Win[c:3c] . bkv + bin[c:3c]).
+    // One [kv_total, c_cond] matrix for all AttnBlocks turns 2 x n_attn tiny GEMMs per sample() call (8 rows at batch 1: 48 launches, 0.57 ms per
+    // image) into ONE weight-streaming launch; equal to the two-stage form up to fp32 rounding of the composed weights.
+    if (m->n_attn > 0) {
+        hipStream_t st = (hipStream_t)stream;
+        const int cc = m->cfg.c_cond;
+        m->kv_col.assign(m->n_attn, 0);
+        int total = 0;
+        for (int i = 0; i < m->n_attn; ++i) { m->kv_col[i] = total; total += 2 * m->attn_c[i]; }
+        m->kv_total = total;
+        if (m->kv_w.p) gemm_unregister_weight(m->kv_w.p);
+        RET_IF(devbuf_alloc(m->kv_w, (size_t)total * cc));
+        RET_IF(devbuf_alloc(m->kv_b, (size_t)total));
+        DevBuf wkv_t;
+        RET_IF(devbuf_alloc(wkv_t, (size_t)cc * m->c_max));
+        void* ws = nullptr;
+        HIP_CHECK_RET(hipMalloc(&ws, kGemmTicketBytes + ((size_t)64 << 20)));
+        int rc = paella_workspace_init(ws, kGemmTicketBytes, st);
+        auto compose = [&](const Block& b) -> int {
+            if (b.type != BT_ATTN) return PAELLA_OK;
+            const int ch = b.c;
+            const float* win = T(m, b.prefix + ".attention.attn.in_proj_weight") + (size_t)ch * ch;  // rows c .. 3c
+            const float* bin = T(m, b.prefix + ".attention.attn.in_proj_bias") + ch;
+            const int64_t shp[2] = {ch, cc};
+            const int perm[2] = {1, 0};
+            RET_IF(launch_permute(T(m, b.prefix + ".kv_mapper.1.weight"), wkv_t.p, shp, perm, 2, st));  // [ch, cc] -> [cc, ch]
+            // kv_w rows [col, col + 2ch): C[2ch, cc] = Win[c:3c] [2ch, ch] . (Wkv^T [cc, ch])^T
+            GemmArgs g = gemm_args(win, ch, wkv_t.p, ch, m->kv_w.p + (size_t)m->kv_col[b.attn_index] * cc, cc, 2 * ch, cc, ch);
+            RET_IF(launch_gemm_cfg(g, 18, 1, ws, kGemmTicketBytes + ((size_t)64 << 20), st));  // (explicit fp32 tile: never the bf16 fast mode)
+            // kv_b: C[1, 2ch] = bkv [1, ch] . Win[c:3c]^T + bin[c:3c]
+            GemmArgs gb = gemm_args(T(m, b.prefix + ".kv_mapper.1.bias"), ch, win, ch, m->kv_b.p + m->kv_col[b.attn_index], 2 * ch, 1, 2 * ch, ch);
+            gb.ep.bias = bin;
+            RET_IF(launch_gemm_cfg(gb, 5, 1, ws, kGemmTicketBytes + ((size_t)64 << 20), st));
+            return PAELLA_OK;
+        };
+        if (rc == PAELLA_OK) for (const Block& b : m->down) { rc = compose(b); if (rc != PAELLA_OK) break; }
+        if (rc == PAELLA_OK) for (const Block& b : m->up) { rc = compose(b); if (rc != PAELLA_OK) break; }
+        if (hipStreamSynchronize(st) != hipSuccess && rc == PAELLA_OK) { paella_set_error("finalize: stream error while composing the conditioning projections"); rc = PAELLA_ERR_HIP; }
+        (void)hipFree(ws);
+        if (wkv_t.p) (void)hipFree(wkv_t.p);
+        if (rc != PAELLA_OK) return rc;
+        RET_IF(gemm_register_weight(m->kv_w.p, m->kv_w.n, st));
+    }
     if (!m->freqs_set) {
         const int half = m->cfg.c_r / 2;
         std::vector<float> f(half > 0 ? half : 1);
@@ -385,17 +436,11 @@ extern "C" int paella_unet_finalize(paella_unet* m, void* stream) {
 }
 
 // ---------------------------------------------------------------------------
-// conditioning cache layout: per attention block i (execution order) a [B*S, 2*c_i] matrix (K | V)
+// conditioning cache layout: ONE row-major matrix [B*S, kv_total]; AttnBlock i (execution order) owns columns [kv_col[i], +2*c_i) = (K | V)
 // ---------------------------------------------------------------------------
-static size_t cond_offset_floats(const paella_unet* m, int i, int B, int S) {
-    size_t off = 0;
-    for (int k = 0; k < i; ++k) off += (((size_t)B * S * 2 * m->attn_c[k]) + 63) & ~(size_t)63;
-    return off;
-}
-
 extern "C" size_t paella_unet_cond_bytes(const paella_unet* m, int B, int S) {
     if (!m) return 0;
-    const size_t n = cond_offset_floats(m, m->n_attn, B, S);
+    const size_t n = (size_t)B * S * (size_t)m->kv_total;
     return (n ? n : 64) * sizeof(float);
 }
 
@@ -404,7 +449,7 @@ struct FwdBuffers {
     float* xu[PAELLA_MAX_LEVELS];
     float *h, *g, *grn_scale, *grn_gx, *ts, *remb, *splitk, *rowstat;
     // cond_prepare
-    float *c_embed, *c_silu, *kvm;
+    float *c_embed, *c_silu;
 };
 
 static int64_t level_rows(const paella_unet* m, int B, int H, int W, int l) {
@@ -448,7 +493,6 @@ static void carve_cond(const paella_unet* m, Arena& a, int B, int S, FwdBuffers&
     f.splitk = a.take(kSplitKBudget / sizeof(float));  // FIRST, as in carve_forward
     f.c_embed = a.take((size_t)B * S * m->cfg.c_cond);
     f.c_silu = a.take((size_t)B * S * m->cfg.c_cond);
-    f.kvm = a.take((size_t)B * S * m->c_max);
 }
 
 extern "C" size_t paella_unet_workspace_bytes(const paella_unet* m, int B, int H, int W, int S) {
@@ -532,22 +576,10 @@ extern "C" int paella_unet_cond_prepare(paella_unet* m, const float* byt5, int S
     RET_IF(compute_c_embed(m, byt5, S_byt5, clip, clip_image, n_clip_image, B, S, f.c_embed, f.splitk, st));
     RET_IF(launch_silu(f.c_embed, f.c_silu, (int64_t)B * S * cc, st));
 
-    // per AttnBlock: kv = kv_mapper(c_embed) (src/modules.py:77), then K|V = kv . in_proj_weight[c:3c]^T + in_proj_bias[c:3c]
-    auto do_block = [&](const Block& b) -> int {
-        if (b.type != BT_ATTN) return PAELLA_OK;
-        const int ch = b.c;
-        GemmArgs g1 = gemm_args(f.c_silu, cc, T(m, b.prefix + ".kv_mapper.1.weight"), cc, f.kvm, ch, B * S, ch, cc);
-        g1.ep.bias = T(m, b.prefix + ".kv_mapper.1.bias");
-        RET_IF(launch_gemm(g1, f.splitk, skb, st));
-        float* dst = (float*)cond_out + cond_offset_floats(m, b.attn_index, B, S);
-        GemmArgs g2 = gemm_args(f.kvm, ch, T(m, b.prefix + ".attention.attn.in_proj_weight") + (size_t)ch * ch, ch, dst, 2 * ch, B * S,
-                                2 * ch, ch);
-        g2.ep.bias = T(m, b.prefix + ".attention.attn.in_proj_bias") + ch;
-        RET_IF(launch_gemm(g2, f.splitk, skb, st));
-        return PAELLA_OK;
-    };
-    for (const Block& b : m->down) RET_IF(do_block(b));
-    for (const Block& b : m->up) RET_IF(do_block(b));
+    // every AttnBlock's kv = kv_mapper(c_embed) (src/modules.py:77) and K|V in-projection of those rows in ONE GEMM over the composed weights
+    GemmArgs g = gemm_args(f.c_silu, cc, m->kv_w.p, cc, (float*)cond_out, m->kv_total, B * S, m->kv_total, cc);
+    g.ep.bias = m->kv_b.p;
+    RET_IF(launch_gemm(g, f.splitk, skb, st));
     return PAELLA_OK;
 }
 
@@ -616,11 +648,11 @@ static int run_attn_block(FwdCtx& cx, const Block& b, float* x, int h, int w) {
     }
     gq.ep.bias = T(m, b.prefix + ".attention.attn.in_proj_bias");
     RET_IF(launch_gemm(gq, cx.f.splitk, kSplitKBudget, cx.st));
-    const float* kv = cx.cond + cond_offset_floats(m, b.attn_index, cx.B, cx.S);
+    const float* kv = cx.cond + m->kv_col[b.attn_index];
     AttnArgs a;
     a.q = cx.f.g; a.ldq = nq;
     a.k_self = self ? cx.f.g + ch : nullptr; a.v_self = self ? cx.f.g + 2 * ch : nullptr; a.ld_self = nq;
-    a.k_cond = kv; a.v_cond = kv + ch; a.ld_cond = 2 * ch;
+    a.k_cond = kv; a.v_cond = kv + ch; a.ld_cond = m->kv_total;
     a.out = cx.f.h; a.ldo = ch;
     a.B = cx.B; a.nhead = nh; a.D = ch / nh; a.Lq = h * w; a.Lself = self ? h * w : 0; a.Lcond = cx.S;
     a.scale = 1.0f / sqrtf((float)(ch / nh));

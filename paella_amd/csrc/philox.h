@@ -25,8 +25,10 @@ __device__ __forceinline__ void philox4x32(uint64_t seed, uint64_t ctr_lo, uint6
     }
     out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
 }
-// (0,1): 24 random bits, never 0 -> -log(u) finite and > 0
-__device__ __forceinline__ float u01_open(uint32_t bits) { return ((float)(bits >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+// (0,1), both ends excluded: 23 random bits + 1/2 is exact in fp32 (24 significant bits), so u lies in [2^-24, 1 - 2^-24] and both logarithms of
+// the Gumbel draw stay finite.  (With 24 bits + 1/2 the top value rounds to 1.0f: log(-log 1) = -inf hands that label a +inf score about once
+// per 2^24 logits -- found in round 3 by the decision-margin test.)
+__device__ __forceinline__ float u01_open(uint32_t bits) { return ((float)(bits >> 9) + 0.5f) * (1.0f / 8388608.0f); }
 // [0,1): torch.rand semantics (24-bit mantissa grid)
 __device__ __forceinline__ float u01_half_open(uint32_t bits) { return (float)(bits >> 8) * (1.0f / 16777216.0f); }
 

@@ -31,6 +31,9 @@ int paella_test_gemm_raster(int gm);
  * single host thread (the events live in a plain vector). */
 int paella_prof_enable(int on);
 int paella_prof_collect(double* total_ms, double* total_flops, double* total_bytes, long long* launches);
+/* per-launch records since enable(1), not reset (call before collect): us_out[i], shape_out[5 i ..] = M, N, K, prologue (0 none, 1 GRN, 2 LayerNorm,
+ * 3 implicit convolution), fused-tail flag; returns the launch count (at most cap are written) */
+long long paella_prof_detail(float* us_out, int* shape_out, long long cap);
 /* scores_out [rows, L] = the Gumbel-max scores of the counter-based sampling tail (mix(l_c, l_u) / T - log q, the kernels' own arithmetic and
  * Philox counters): tests classify a differing token by the decision margin between the two best scores of its row */
 int paella_test_tail_scores(const float* logits_c, const float* logits_u, long long rows, int L, float cfg, float one_minus_cfg, float temperature,

@@ -1,0 +1,64 @@
+"""Per-shape GEMM time INSIDE the model: one eager image of the headline workload with every dense-contraction launch bracketed by HIP events
+(paella_prof_detail), grouped by (M, N, K, prologue).  Usage (GPU box): python tools/gemm_by_shape.py [--batch B --grid G --sample-steps S]"""
+import argparse
+import collections
+import ctypes
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import bench
+import paella_amd
+from paella_amd import _lib, synth
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=1)
+ap.add_argument("--grid", type=int, default=32)
+ap.add_argument("--sample-steps", type=int, default=8)
+a = ap.parse_args()
+lib = _lib.load()
+dev = torch.device("cuda")
+mcfg, vcfg = bench.MODELS["570m"], bench.VQ["570m"]
+model = paella_amd.Paella(**mcfg)
+synth.randomize_(model, seed=0)
+model = model.to(dev)
+vq = paella_amd.VQModel(**vcfg)
+synth.randomize_(vq, seed=0)
+vq = vq.to(dev)
+mk = lambda n, seed: synth.synth_conditioning(n, 0, mcfg["byt5_embd"], mcfg["clip_embd"], seed=seed, device=dev)
+c, u = mk(a.batch, 2), mk(a.batch, 3)
+kw = dict(steps=a.sample_steps, renoise_steps=a.sample_steps - 1, temperature=(1.0, 0.2), cfg=8.0, device=dev, noise="philox")
+
+
+def once(seed):
+    toks = paella_amd.sample(model, c, (a.batch, a.grid, a.grid), unconditional_inputs=u, seed=seed, **kw)
+    return vq.decode_indices(toks)
+
+
+once(1)
+once(2)
+torch.cuda.synchronize()
+lib.paella_prof_enable(1)
+once(3)
+torch.cuda.synchronize()
+cap = 1 << 16
+us = np.zeros(cap, dtype=np.float32)
+shp = np.zeros(cap * 5, dtype=np.int32)
+n = lib.paella_prof_detail(us.ctypes.data_as(ctypes.c_void_p), shp.ctypes.data_as(ctypes.c_void_p), cap)
+lib.paella_prof_enable(0)
+shp = shp[:n * 5].reshape(n, 5)
+groups = collections.OrderedDict()
+for t, s in zip(us[:n], shp):
+    groups.setdefault(tuple(int(v) for v in s), []).append(float(t))
+names = {0: "plain", 1: "GRN", 2: "LN", 3: "conv"}
+print("# python tools/gemm_by_shape.py --batch %d --grid %d --sample-steps %d: %d GEMM launches per image batch, event-timed, eager; per (M, N, K, prologue)" % (a.batch, a.grid, a.sample_steps, n))
+print("%-8s %-7s %-7s %-6s %6s %9s %9s %9s %7s" % ("M", "N", "K", "pro", "calls", "avg us", "min us", "total ms", "TF/s"))
+tot = 0.0
+for (M, N, K, pro, tail), ts in sorted(groups.items(), key=lambda kv: -sum(kv[1])):
+    tt = sum(ts)
+    tot += tt
+    print("%-8d %-7d %-7d %-6s %6d %9.2f %9.2f %9.3f %7.1f" % (M, N, K, names[pro] + ("+tail" if tail else ""), len(ts), tt / len(ts), min(ts), tt / 1e3, 2.0 * M * N * K * len(ts) / tt / 1e6))
+print("total %.3f ms over %d launches" % (tot / 1e3, n))
