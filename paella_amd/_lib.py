@@ -100,6 +100,7 @@ TEST_HOOKS = {
     "paella_test_gemm_dma": (c_int, [c_int]),
     "paella_test_gemm_raster": (c_int, [c_int]),
     "paella_test_gemm_ring": (c_int, [c_int]),
+    "paella_test_mlp_grn_fused": (c_int, [c_void_p] * 10 + [c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "paella_test_gemm_tail_tile": (c_int, [c_int]),
     "paella_test_tail_scores": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, c_float, c_float, c_uint64, c_uint64, c_int64, c_void_p, c_void_p]),
     "paella_test_gemm_prologue": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,

@@ -57,6 +57,12 @@ struct Epilogue {
     int n_seg_x;            // STORE_D2S: segments along n are (dy,dx) with dx in [0,n_seg_x); 2 for k2s2, 1 for a phase
     float* rowstat_out;     // optional [M, N/16, 2]: per row and 16-column block, (sum, sum of squares) of the stored values (LayerNorm-on-load)
     float* sumsq_out;       // optional [ceil(M/16), N]: per 16-row group, column sums of the stored values squared (GRN)
+    // optional (ring tiles whose rows cover whole samples: grn_rps == 16 or == the tile height): GlobalResponseNorm's Gx finished IN this epilogue --
+    // grn_gx_out [samples, N] = sqrt(sum over the sample's rows of value^2) and grn_part_out [samples, grn_np] = per (column tile, wave column) sums of
+    // Gx, so the consuming GEMM derives mean_k Gx from grn_np numbers instead of waiting for a finalize launch between the two MLP GEMMs
+    float* grn_gx_out;
+    float* grn_part_out;
+    int grn_rps, grn_np;
     int remap_in, remap_out, remap_off;  // STORE_PLAIN, remap_in > 0: out row = (m/remap_in)*remap_out + m%remap_in + remap_off
 };
 
@@ -65,6 +71,7 @@ static inline Epilogue make_epilogue() {
     e.bias = nullptr; e.act = ACT_NONE; e.alpha = 1.f; e.residual = nullptr; e.ldr = 0;
     e.ts = nullptr; e.ts_stride = 0; e.rows_per_sample = 1; e.store_mode = STORE_PLAIN;
     e.sH = e.sW = e.sC = 0; e.py = e.px = 0; e.n_seg_x = 2; e.remap_in = e.remap_out = e.remap_off = 0; e.sumsq_out = nullptr; e.rowstat_out = nullptr;
+    e.grn_gx_out = nullptr; e.grn_part_out = nullptr; e.grn_rps = 0; e.grn_np = 0;
     return e;
 }
 
@@ -103,6 +110,13 @@ struct GemmArgs {
     const float* a_scale;      // [samples, K] or null
     const float* a_shift;      // [K]
     int a_rows_per_sample;
+    // or (ring tiles only) the same apply from the producer's UNFINISHED statistics: a' = a * (1 + gamma[k] * gx[b][k] / (mean_k gx[b][:] + 1e-6)) + shift[k],
+    // mean from grn_part [samples, grn_np] (Epilogue::grn_part_out of the GEMM that produced A); a_rows_per_sample as above
+    const float* grn_gx;       // [samples, K] or null
+    const float* grn_gamma;    // [K]
+    const float* grn_part;     // [samples, grn_np]
+    int grn_np;
+    int force_ring_cfg;        // > 0: the launch heuristic uses this ring tile for a skinny problem (the producer of grn_gx must cover whole samples)
     // or (exclusive with a_scale) LayerNorm of the A rows from producer statistics: a' = (a - mean[m]) * rstd[m],
     // mean/var combined from ln_stats [M, ln_nblk, 2] (Epilogue::rowstat_out of the GEMM that produced A), K == 16*ln_nblk
     const float* ln_stats;
@@ -125,6 +139,9 @@ int launch_gemm(const GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t stream
 // (classic split-K); splitk < 0: exactly -splitk workgroups (balanced contiguous unit ranges).
 int launch_gemm_cfg(const GemmArgs& g, int cfg, int splitk, void* ws, size_t ws_bytes, hipStream_t stream);
 int gemm_num_tile_configs();
+// ring tile the first MLP GEMM must run on so that its epilogue finishes GlobalResponseNorm's Gx (Epilogue::grn_gx_out) and the second one can apply it
+// straight from those statistics (GemmArgs::grn_gx): 0 = not applicable (use the grn_from_partials finalize launch)
+int gemm_grn_fused_tile(int M, int C4, int C, int rows_per_sample, bool allow_64);
 // Head GEMM with the fused tail epilogue: one whole tile per workgroup; g.ft.part_* are [M, gemm_tail_tiles_n(M, N)].
 int gemm_tail_tiles_n(int M, int N);
 int launch_gemm_tail(const GemmArgs& g, hipStream_t stream);

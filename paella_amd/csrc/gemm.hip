@@ -92,6 +92,8 @@ extern "C" int paella_probe_gemm_clock(unsigned long long* out2) {
 
 template <int WM, int WN, int TM, int TN, int PD, int APRO, bool TAIL = false, int BK = 32, bool DMA = false, int RING = 0>  // BK: K step (32 or 64 floats per LDS row); APRO: 0 none, 1 GRN scale/shift, 2 LayerNorm from row statistics; TAIL: fused sampling tail (head GEMM);
 // DMA: operands that need no transform (W always, A when APRO == 0) go global -> LDS directly (buffer_load ... lds), no staging registers, no ds_write pass
+// APRO 4 (ring tiles only): the GRN apply from the producer's UNFINISHED statistics -- a' = a * (1 + gamma * gx / (mean gx + 1e-6)) + shift, the mean
+// derived per workgroup from the producer's per-column-tile partial sums (no finalize launch between the two MLP GEMMs).
 // RING > 0 (the batch-1 kernels): BOTH operands always go global -> LDS directly into a ring of RING stages with RING - 1 units in flight per workgroup
 // (the prefetch depth costs LDS, not registers), and an A-operand prologue is applied to the MFMA FRAGMENTS after they are read back from LDS (GRN scale /
 // shift rows ride along in a 2 KB side stage; LayerNorm mean / rstd live in two registers per fragment row).  One barrier per unit, no ds_write at all.
@@ -121,14 +123,18 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (TM * TN == 1 ? (RING == 3
     static_assert(!DMA || (PD == 1 && BK == 32 && !TAIL && (BM * SL) % NT == 0 && (BN * SL) % NT == 0), "DMA variant: 1-deep, K step 32, whole passes");
     static_assert(RING == 0 || (RING >= 3 && RING <= 4 && !DMA && PD == 1 && BK == 32 && !TAIL && APRO != 3 && NW == 4 && (BM * SL) % NT == 0 && (BN * SL) % NT == 0),
                   "ring variant: 3 or 4 LDS stages, 4 waves, K step 32, whole passes, no implicit convolution");
-    // ring stage = the A and W tiles + (GRN prologue) a 2 KB side stage: 8 copies of shift[k0 .. k0 + 32) | scale rows of 8 consecutive samples
-    constexpr int AUX_FLOATS = (RING > 0 && APRO == 1) ? 512 : 0;
+    static_assert(APRO != 4 || RING > 0, "the GRN-from-raw-statistics prologue exists on ring tiles only");
+    constexpr bool GRN_SIDE = RING > 0 && (APRO == 1 || APRO == 4);
+    // ring stage = the A and W tiles + (GRN prologues) a side stage: 8 copies of shift[k0 .. k0 + 32) | scale rows of 8 consecutive samples (APRO 1), or
+    // (APRO 4, exec-masked DMAs that move 128 bytes each) shift[k0 .. +32) | gamma[k0 .. +32) | gx rows of 8 consecutive samples
+    constexpr int AUX_FLOATS = (RING > 0 && APRO == 1) ? 512 : ((RING > 0 && APRO == 4) ? 320 : 0);
+    constexpr int GRN_SCR = RING > 0 ? WM * WN * TN * 16 : 0;  // epilogue scratch: per-wave column sums of squares when a sample spans several waves' rows
     constexpr int STAGE_FLOATS = TILE_FLOATS + AUX_FLOATS;
     constexpr int FLAG_OFF = RING > 0 ? RING * STAGE_FLOATS : 2 * TILE_FLOATS;  // 16 floats for the ticket broadcast behind the stages
     // one LDS object: two tile stages + 16 floats for the ticket broadcast (the NEXT unit's tile is already staged when a
     // segment is flushed, so the flag cannot live inside the stages)
     constexpr int TAIL_FLOATS = TAIL ? BM * WN * 2 : 0;  // fused tail: per row and wave column, the best (score, label)
-    __shared__ __attribute__((aligned(16))) float smem[FLAG_OFF + 16 + TAIL_FLOATS];
+    __shared__ __attribute__((aligned(16))) float smem[FLAG_OFF + 16 + TAIL_FLOATS + GRN_SCR];
 
     // ---- this workgroup's unit range ----
     const unsigned G = gridDim.x;
@@ -191,7 +197,8 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (TM * TN == 1 ? (RING == 3
     const size_t w_bytes = ((size_t)(g.N - 1) * g.ldw + g.K) * sizeof(float);
     __amdgpu_buffer_rsrc_t rsrcA = rsrc_of(g.A, a_bytes), rsrcW = rsrc_of(g.W, w_bytes);
     __amdgpu_buffer_rsrc_t rsrcS = rsrc_of(g.A, 16);
-    const __amdgpu_buffer_rsrc_t rsrcT = rsrc_of(APRO == 1 ? g.a_shift : g.A, APRO == 1 ? (size_t)g.K * sizeof(float) : 16);
+    const __amdgpu_buffer_rsrc_t rsrcT = rsrc_of((APRO == 1 || APRO == 4) ? g.a_shift : g.A, (APRO == 1 || APRO == 4) ? (size_t)g.K * sizeof(float) : 16);
+    const __amdgpu_buffer_rsrc_t rsrcG = rsrc_of(APRO == 4 ? g.grn_gamma : g.A, APRO == 4 ? (size_t)g.K * sizeof(float) : 16);
     unsigned aoff[LA], soff[APRO == 1 ? LA : 1], boff[LB];
     unsigned aux_s_off = 0;  // ring + GRN prologue: this lane's source offset in the scale rows of the tile's samples (lane -> sample lane / 8, 16-byte chunk lane % 8)
     int cy[APRO == 3 ? LA : 1], cx[APRO == 3 ? LA : 1];  // implicit conv: top-left input coordinate of row i (aoff[i] = image base position)
@@ -212,10 +219,10 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (TM * TN == 1 ? (RING == 3
         rsrcA = rsrc_of(reinterpret_cast<const float*>(reinterpret_cast<const char*>(g.A) + a_base), a_bytes - a_base);
         const size_t w_base = (size_t)n0 * g.ldw * sizeof(float);
         rsrcW = rsrc_of(reinterpret_cast<const float*>(reinterpret_cast<const char*>(g.W) + w_base), w_bytes - w_base);
-        if (APRO == 1) {
+        if (APRO == 1 || APRO == 4) {
             smp0 = m0 / g.a_rows_per_sample;
             const size_t s_bytes = (size_t)((g.M - 1) / g.a_rows_per_sample + 1) * g.K * sizeof(float), s_base = (size_t)smp0 * g.K * sizeof(float);
-            rsrcS = rsrc_of(g.a_scale + (size_t)smp0 * g.K, s_bytes - s_base);
+            rsrcS = rsrc_of((APRO == 4 ? g.grn_gx : g.a_scale) + (size_t)smp0 * g.K, s_bytes - s_base);
         }
 #pragma unroll
         for (int i = 0; i < LA; ++i) {
@@ -232,7 +239,7 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (TM * TN == 1 ? (RING == 3
             }
             if (APRO == 1 && RING == 0) soff[i] = ((unsigned)(gmc / g.a_rows_per_sample - smp0) * (unsigned)g.K + (unsigned)(ldc4 * 4)) * 4u;
         }
-        if (APRO == 1 && RING > 0) {
+        if (GRN_SIDE) {
             const int last = (g.M - 1) / g.a_rows_per_sample - smp0;  // clamp: rows past the last sample re-read it (never used)
             aux_s_off = ((unsigned)min(lane_k >> 3, last) * (unsigned)g.K + (unsigned)((lane_k & 7) * 4)) * 4u;
         }
@@ -277,10 +284,18 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (TM * TN == 1 ? (RING == 3
             for (int i = 0; i < LA; ++i) dma_b128_to_lds(rsrcA, dAs + i * RP * BK, aoff[i], kofs);
 #pragma unroll
             for (int i = 0; i < LB; ++i) dma_b128_to_lds(rsrcW, dBs + i * RP * BK, boff[i], kofs);
-            if (APRO == 1 && wave == NW - 1) {  // the side stage: 1 KB of shift (8 copies of the 128-byte row), 1 KB of scale rows
+            if (GRN_SIDE && wave == NW - 1) {  // the side stage: 1 KB of shift (8 copies of the 128-byte row) [, 1 KB of gamma], 1 KB of scale / gx rows
                 float* dX = smem + dma_slot * STAGE_FLOATS + TILE_FLOATS;
-                dma_b128_to_lds(rsrcT, dX, (unsigned)((lane_k & 7) * 16), kofs);
-                dma_b128_to_lds(rsrcS, dX + 256, aux_s_off, kofs);
+                if (APRO == 4) {  // lanes 0..7 only: one 128-byte row each of shift and gamma (an LDS-DMA writes M0 + lane * 16 for the ACTIVE lanes)
+                    if (lane_k < 8) {
+                        dma_b128_to_lds(rsrcT, dX, (unsigned)(lane_k * 16), kofs);
+                        dma_b128_to_lds(rsrcG, dX + 32, (unsigned)(lane_k * 16), kofs);
+                    }
+                    dma_b128_to_lds(rsrcS, dX + 64, aux_s_off, kofs);
+                } else {
+                    dma_b128_to_lds(rsrcT, dX, (unsigned)((lane_k & 7) * 16), kofs);
+                    dma_b128_to_lds(rsrcS, dX + 256, aux_s_off, kofs);
+                }
             }
             return;
         }
@@ -490,6 +505,8 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (TM * TN == 1 ? (RING == 3
             __syncthreads();  // the scratch is reused by this workgroup's next tile
             return;
         }
+        f32x4 qq[RING > 0 ? TM : 1][RING > 0 ? TN : 1];  // ring tiles: per 16-row block, column sums of squares (GRN finished in the epilogue)
+        const bool grn_fin = RING > 0 && g.ep.grn_gx_out != nullptr;  // kernel-uniform
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int m = m0 + (wm * TM + i) * 16 + r16;
@@ -501,6 +518,19 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (TM * TN == 1 ? (RING == 3
                 if (ok) {
                     v = epilogue_apply(g.ep, g.N, m, nn, acc[i][j]);
                     epilogue_write(g.ep, g.C, g.ldc, m, nn, v);
+                }
+                if constexpr (RING > 0) {
+                    if (grn_fin) {
+                        f32x4 q = v * v;
+#pragma unroll
+                        for (int o = 1; o < 16; o <<= 1) {
+                            q[0] += __shfl_xor(q[0], o, 64);
+                            q[1] += __shfl_xor(q[1], o, 64);
+                            q[2] += __shfl_xor(q[2], o, 64);
+                            q[3] += __shfl_xor(q[3], o, 64);
+                        }
+                        qq[i][j] = q;  // every lane of the 16-row group holds the group's column sums (columns nn .. nn + 3)
+                    }
                 }
                 if (g.ep.sumsq_out) {  // kernel-uniform: per-16-row column sums of squares (GlobalResponseNorm statistics)
                     f32x4 q = v * v;
@@ -524,6 +554,62 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (TM * TN == 1 ? (RING == 3
                         float* dstp = g.ep.rowstat_out + ((size_t)m * (g.N >> 4) + (nb >> 4)) * 2;
                         dstp[0] = rs; dstp[1] = rq;
                     }
+                }
+            }
+        }
+        if constexpr (RING > 0) {
+            if (grn_fin) {
+                // GlobalResponseNorm's Gx[sample][column] = sqrt(sum over the sample's rows of value^2) finished HERE (reference src/modules.py:37), plus the
+                // sum of Gx over this wave's columns -- the consumer adds grn_np such numbers per sample for mean_k Gx.  The host launches this only
+                // with tiles whose rows cover whole samples: rows per sample == 16 (every 16-row block is a sample) or == the tile height.
+                const int rps = g.ep.grn_rps;
+                const int tile_n_id = n0 / BN;
+                auto finish = [&](const f32x4 (&qs)[TN], int sample, bool valid) __attribute__((always_inline)) {
+                    float wsum = 0.f;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const int nn = n0 + (wn * TN + j) * 16 + kq * 4;
+                        f32x4 gx;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) gx[e] = sqrtf(qs[j][e]);
+                        if (nn < g.N) {
+                            if (r16 == 0 && valid) *reinterpret_cast<f32x4*>(g.ep.grn_gx_out + (size_t)sample * g.N + nn) = gx;
+                            wsum += (gx[0] + gx[1]) + (gx[2] + gx[3]);
+                        }
+                    }
+                    wsum += __shfl_xor(wsum, 16, 64);  // the four column quads of the 16-column block(s)
+                    wsum += __shfl_xor(wsum, 32, 64);
+                    if (r16 == 0 && kq == 0 && valid) g.ep.grn_part_out[(size_t)sample * g.ep.grn_np + tile_n_id * WN + wn] = wsum;
+                };
+                if (rps == 16) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const int mg = m0 + (wm * TM + i) * 16;
+                        finish(qq[i], mg >> 4, mg < g.M);
+                    }
+                } else {  // rps == BM: one sample per tile; add the 16-row blocks of this wave, then the waves stacked along M (fixed order)
+                    f32x4 qt[TN];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        qt[j] = qq[0][j];
+#pragma unroll
+                        for (int i = 1; i < TM; ++i) qt[j] += qq[i][j];
+                    }
+                    if (WM > 1) {
+                        float* scr = smem + FLAG_OFF + 16 + TAIL_FLOATS;
+                        if (wm > 0 && r16 == 0) {
+#pragma unroll
+                            for (int j = 0; j < TN; ++j) *reinterpret_cast<f32x4*>(scr + ((wm * WN + wn) * TN + j) * 16 + kq * 4) = qt[j];
+                        }
+                        __syncthreads();
+                        if (wm == 0) {
+                            for (int w = 1; w < WM; ++w)
+#pragma unroll
+                                for (int j = 0; j < TN; ++j) qt[j] += *reinterpret_cast<const f32x4*>(scr + ((w * WN + wn) * TN + j) * 16 + kq * 4);
+                        }
+                        __syncthreads();  // the scratch is reused by this workgroup's next tile
+                    }
+                    if (wm == 0) finish(qt, m0 / rps, m0 < g.M);
                 }
             }
         }
@@ -601,14 +687,32 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (TM * TN == 1 ? (RING == 3
     int loaded = 0;  // units fetched so far; the load cursor stops on the range's last unit (re-reading it hits L1/L2)
     if constexpr (RING > 0) {
         // ===== ring variant: RING LDS stages, RING - 1 units in flight, both operands by LDS-DMA, prologue on the fragments =====
-        int sidx[(APRO == 1) ? TM : 1];  // GRN prologue: sample (relative to the tile's first) of this lane's fragment rows
+        int sidx[GRN_SIDE ? TM : 1];      // GRN prologues: sample (relative to the tile's first) of this lane's fragment rows
+        float rinv[(APRO == 4) ? TM : 1];  // APRO 4: 1 / (mean_k gx[sample][:] + 1e-6) of those samples
+        int rinv_tile_m = -1;
         auto enter_tile = [&](int tile) __attribute__((always_inline)) {
-            if (APRO != 1) return;
+            if (!GRN_SIDE) return;
             int tile_m, tile_n;
             sk_tile_coords<(BM >= 64)>(p, tile, tile_m, tile_n);
             const int m0 = tile_m * BM, smp0 = m0 / g.a_rows_per_sample;
 #pragma unroll
             for (int i = 0; i < TM; ++i) sidx[i] = min(m0 + (wm * TM + i) * 16 + r16, g.M - 1) / g.a_rows_per_sample - smp0;
+            if (APRO == 4 && tile_m != rinv_tile_m) {
+                // mean_k gx of the fragment rows' samples from the producer's per-(column tile, wave column) partial sums: the host guarantees
+                // a_rows_per_sample % 16 == 0, so the 16 rows of a fragment belong to ONE sample and the whole wave reduces its grn_np numbers
+                // (lane-strided loads, xor butterfly: fixed order, every workgroup gets the same bits)
+                rinv_tile_m = tile_m;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int smp = __builtin_amdgcn_readfirstlane(smp0 + sidx[i]);
+                    const float* sp = g.grn_part + (size_t)smp * g.grn_np;
+                    float sm = 0.f;
+                    for (int j = lane_k; j < g.grn_np; j += 64) sm += sp[j];
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
+                    rinv[i] = 1.0f / (sm / (float)g.K + 1e-6f);
+                }
+            }
         };
         auto compute_ring = [&](int cs) __attribute__((always_inline)) {
             const float* As = smem + cs * STAGE_FLOATS;
@@ -637,6 +741,21 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (TM * TN == 1 ? (RING == 3
 #pragma unroll
                     for (int i = 0; i < TM; ++i) {
                         const f32x4 sc = *reinterpret_cast<const f32x4*>(X + 256 + sidx[i] * 32 + c4 * 4);
+                        af[kk][i] = af[kk][i] * sc + t;
+                    }
+                }
+            }
+            if (APRO == 4) {  // a' = a * (1 + gamma * gx * rinv) + shift  (reference src/modules.py:36-40: gamma * (x * nx) + beta + x, nx = gx / (mean gx + 1e-6))
+                const float* X = Bs + BN * BK;
+#pragma unroll
+                for (int kk = 0; kk < KG; ++kk) {
+                    const int c4 = kk * 4 + kq;
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(X + c4 * 4);
+                    const f32x4 gm = *reinterpret_cast<const f32x4*>(X + 32 + c4 * 4);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const f32x4 gx = *reinterpret_cast<const f32x4*>(X + 64 + sidx[i] * 32 + c4 * 4);
+                        const f32x4 sc = gm * gx * rinv[i] + 1.0f;
                         af[kk][i] = af[kk][i] * sc + t;
                     }
                 }
@@ -677,7 +796,8 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (TM * TN == 1 ? (RING == 3
                 }
             }
         };
-        constexpr int PER_UNIT = LA + LB;  // LDS-DMA instructions per unit and wave; the last wave issues 2 more with the GRN side stage
+        constexpr int PER_UNIT = LA + LB;  // LDS-DMA instructions per unit and wave; the last wave issues 2 (APRO 1) / 3 (APRO 4) more with the GRN side stage
+        constexpr int SIDE_DMAS = APRO == 4 ? 3 : 2;
 #pragma unroll
         for (int j = 0; j < RING - 1; ++j) fetch_ring(j);
         if (APRO == 2) {
@@ -721,7 +841,7 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (TM * TN == 1 ? (RING == 3
             for (int s2 = 0; s2 < seg_len; ++s2) {
                 // this wave's share of the oldest unit has landed; the barrier then publishes every wave's share -- and guarantees that all
                 // waves are done reading stage `ls` (the unit computed one iteration ago), which the next DMA overwrites
-                if (APRO == 1 && wave == NW - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 2) * (PER_UNIT + 2)) : "memory");
+                if (GRN_SIDE && wave == NW - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 2) * (PER_UNIT + SIDE_DMAS)) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 2) * PER_UNIT) : "memory");
                 // a bare s_barrier: __syncthreads() carries a workgroup-scope fence, which drains EVERY LDS-DMA in flight (vmcnt(0)) and would
                 // collapse the ring to one unit.  The fragment reads of the previous unit were consumed by its MFMAs, so nothing else is pending.
@@ -903,7 +1023,9 @@ extern "C" int paella_test_gemm_dma(int on) { g_gemm_dma = on != 0; return PAELL
 
 template <int TM, int TN, int RING>
 static void launch_ring(const GemmArgs& g, const SkPlan& p, unsigned G, float* slabs, unsigned* tickets, unsigned slab_bytes, hipStream_t st) {
-    if (g.a_scale)
+    if (g.grn_gx)
+        hipLaunchKernelGGL((gemm_nt_kernel<2, 2, TM, TN, 1, 4, false, 32, false, RING>), dim3(G), dim3(256), 0, st, g, p, slabs, tickets, slab_bytes);
+    else if (g.a_scale)
         hipLaunchKernelGGL((gemm_nt_kernel<2, 2, TM, TN, 1, 1, false, 32, false, RING>), dim3(G), dim3(256), 0, st, g, p, slabs, tickets, slab_bytes);
     else if (g.ln_stats)
         hipLaunchKernelGGL((gemm_nt_kernel<2, 2, TM, TN, 1, 2, false, 32, false, RING>), dim3(G), dim3(256), 0, st, g, p, slabs, tickets, slab_bytes);
@@ -944,7 +1066,7 @@ static void launch_one(const GemmArgs& g, const SkPlan& p, unsigned G, float* sl
 // ring tiles: both operands by LDS-DMA (whole K steps only), GRN side stage holds the scale rows of at most 8 consecutive samples
 static bool ring_ok(const GemmArgs& g, int BM) {
     if (g.K % 32 || g.cv.enabled) return false;
-    if (g.a_scale && (BM - 1) / (g.a_rows_per_sample > 0 ? g.a_rows_per_sample : 1) + 2 > 8) return false;
+    if ((g.a_scale || g.grn_gx) && (BM - 1) / (g.a_rows_per_sample > 0 ? g.a_rows_per_sample : 1) + 2 > 8) return false;
     return true;
 }
 static inline long tiles_of_cfg(int c, int M, int N) {
@@ -973,6 +1095,24 @@ extern "C" int paella_test_gemm_ring(int cfg) {
     g_gemm_ring = cfg;
     return PAELLA_OK;
 }
+// The MLP pair gelu(h W1^T) -> GRN -> W2 of one ResBlock / FeedForwardBlock can skip the GRN finalize launch when (a) both GEMMs are in the skinny class
+// the ring tiles serve, (b) the producer's tile rows cover whole samples: 16 rows per sample -> any ring tile (32x32 here), 64 -> the 64x32 tile.
+// Returns the ring tile GEMM1 must use (its grn_np is then (N1 / 32) * 2), or 0.
+// Measured in the model (profiles/r03_gemm_by_shape_b1_grn_fused.txt): at 16 rows per sample the pair costs +1.5 us and saves a ~6 us launch; at 64 rows
+// per sample the 64x32 producer tile (4 parts per tile to combine instead of 2, cross-wave reduction in the epilogue) costs +7.6 us -- more than the
+// launch it removes -- so the model asks with allow_64 = false and keeps the finalize launch there.
+int gemm_grn_fused_tile(int M, int C4, int C, int rows_per_sample, bool allow_64) {
+    static const int enabled = []() { const char* e = getenv("PAELLA_GRN_FUSE"); return e ? atoi(e) : 1; }();  // A/B switch
+    if (!enabled || !g_gemm_ring.load(std::memory_order_relaxed) || gemm_precision() != 0) return 0;
+    if ((C & 31) || (C4 & 31) || M % rows_per_sample) return 0;
+    const double macs = (double)M * C4 * C;
+    const long T64 = (long)((M + 63) / 64) * ((C4 + 63) / 64);
+    if (macs >= 1.2e9 || T64 >= 1024) return 0;  // the launch heuristic leaves the skinny class there
+    if (rows_per_sample == 16) return 30;
+    if (rows_per_sample == 64 && allow_64) return 33;
+    return 0;
+}
+
 // workgroups of a ring tile that are resident at once (LDS-limited; profiles/r03_gemm_ring_resources.txt)
 static long ring_resident(int cfg, int apro) {
     switch (cfg) {
@@ -983,8 +1123,9 @@ static long ring_resident(int cfg, int apro) {
     }
 }
 
-static void choose_config(int M, int N, int K, int apro, bool ring_allowed, size_t slab_cap_bytes, int* cfg_out, unsigned* G_out) {
-    const int g_gemm_ring = ::g_gemm_ring.load(std::memory_order_relaxed);  // one consistent value per decision
+static void choose_config(int M, int N, int K, int apro, bool ring_allowed, int force_ring, size_t slab_cap_bytes, int* cfg_out, unsigned* G_out) {
+    // one consistent value per decision; force_ring: the caller needs THIS ring tile in the skinny class (its epilogue finishes GRN per tile)
+    const int g_gemm_ring = ::g_gemm_ring.load(std::memory_order_relaxed) ? (force_ring > 0 ? force_ring : ::g_gemm_ring.load(std::memory_order_relaxed)) : 0;
     const long ktiles = (K + 31) / 32;
     const double macs = (double)M * N * K;
     const long T128 = tiles_of_cfg(10, M, N), T64 = tiles_of_cfg(18, M, N), T32 = tiles_of_cfg(5, M, N);
@@ -1173,7 +1314,7 @@ static int launch_gemm_cfg_impl(const GemmArgs& g, int cfg, int splitk, void* ws
     const size_t slab_cap = have_ws ? ws_bytes - kGemmTicketBytes : 0;
     unsigned G = 0;
     if (cfg < 0) {
-        choose_config(g.M, g.N, g.K, g.a_scale ? 1 : (g.ln_stats ? 2 : 0), ring_ok(g, 64), slab_cap, &cfg, &G);
+        choose_config(g.M, g.N, g.K, (g.a_scale || g.grn_gx) ? 1 : (g.ln_stats ? 2 : 0), ring_ok(g, 64), g.force_ring_cfg, slab_cap, &cfg, &G);
         if (g.cv.enabled && !conv_cfg(cfg)) { paella_set_error("internal: heuristic picked tile %d without a convolution variant", cfg); return PAELLA_ERR_STATE; }
     } else {
         if (cfg >= kNumCfgs) { paella_set_error("gemm: bad tile config %d", cfg); return PAELLA_ERR_ARG; }
@@ -1183,6 +1324,15 @@ static int launch_gemm_cfg_impl(const GemmArgs& g, int cfg, int splitk, void* ws
     }
     const TileCfg& tc = kCfgs[cfg];
     const int BM = tc.wm * tc.tm * 16, BN = tc.wn * tc.tn * 16;
+    if ((g.grn_gx || g.ep.grn_gx_out) && !tc.ring) { paella_set_error("gemm: the in-epilogue / on-load GRN statistics need a ring tile (got tile %d)", cfg); return PAELLA_ERR_STATE; }
+    if (g.grn_gx && (!g.grn_gamma || !g.a_shift || !g.grn_part || g.grn_np <= 0 || g.a_scale || g.ln_stats || g.a_rows_per_sample % 16)) {
+        paella_set_error("gemm: bad GRN-from-statistics operand description"); return PAELLA_ERR_ARG;
+    }
+    if (g.ep.grn_gx_out && (!g.ep.grn_part_out || !(g.ep.grn_rps == 16 || g.ep.grn_rps == BM) || g.M % g.ep.grn_rps ||
+                            g.ep.grn_np != ((g.N + BN - 1) / BN) * tc.wn)) {
+        paella_set_error("gemm: in-epilogue GRN needs tiles that cover whole samples (rows per sample 16 or %d, got %d) and grn_np = tiles_n * %d", BM, g.ep.grn_rps, tc.wn);
+        return PAELLA_ERR_ARG;
+    }
     if (tc.ring && !ring_ok(g, BM)) { paella_set_error("gemm: tile config %d (LDS-DMA ring) needs K %% 32 == 0, no implicit convolution and <= 8 samples per tile", cfg); return PAELLA_ERR_ARG; }
     SkPlan p;
     p.tiles_m = (g.M + BM - 1) / BM;

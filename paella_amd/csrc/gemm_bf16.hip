@@ -330,7 +330,7 @@ static void launch_b(const GemmArgs& g, const unsigned short* Wb, int kslice, in
 // (no shadow copy, K % 8 != 0): the caller then runs the fp32 kernel.
 int launch_gemm_bf16(const GemmArgs& g, int tile, int splitk, void* ws, size_t ws_bytes, hipStream_t st) {
     const unsigned short* Wb = shadow_lookup(g.W);
-    if (!Wb || (g.K & 7) || (g.ldw & 7) || (g.lda & 3) || (g.N & 3)) return PAELLA_ERR_STATE;
+    if (!Wb || (g.K & 7) || (g.ldw & 7) || (g.lda & 3) || (g.N & 3) || g.grn_gx || g.ep.grn_gx_out) return PAELLA_ERR_STATE;
     if (g.M <= 0 || g.N <= 0) return PAELLA_OK;
     auto tiles_of = [&](int b) { return (long)((g.M + b - 1) / b) * ((g.N + b - 1) / b); };
     const int ktiles = (g.K + 63) / 64;

@@ -609,6 +609,28 @@ static int run_mlp_block(FwdCtx& cx, const Block& b, float* x, const float* skip
     GemmArgs g1 = gemm_args(cx.f.h, ch, T(m, b.prefix + ".channelwise.0.weight"), ch, cx.f.g, 4 * ch, (int)rows, 4 * ch, ch);
     g1.ep.bias = T(m, b.prefix + ".channelwise.0.bias");
     g1.ep.act = ACT_GELU;
+    const int fused_tile = (rps % 16 == 0) ? gemm_grn_fused_tile((int)rows, 4 * ch, ch, rps, false) : 0;
+    if (fused_tile) {
+        // GlobalResponseNorm with NO launch of its own (batch-1 regime): GEMM1's tiles cover whole samples, so its epilogue finishes
+        // Gx[b][k] = ||g[b, :, k]||_2 and leaves per-column-tile sums of Gx; GEMM2 derives mean_k Gx from those and applies
+        // g * (1 + gamma * Gx / (mean + 1e-6)) + beta to its operand fragments (reference src/modules.py:36-40)
+        const int np = (4 * ch / 32) * 2;  // (column tiles of 32) x (2 wave columns)
+        g1.ep.grn_gx_out = cx.f.grn_scale; g1.ep.grn_part_out = cx.f.grn_gx; g1.ep.grn_rps = rps; g1.ep.grn_np = np;
+        g1.force_ring_cfg = fused_tile;
+        RET_IF(launch_gemm(g1, cx.f.splitk, kSplitKBudget, cx.st));
+        GemmArgs g2 = gemm_args(cx.f.g, 4 * ch, T(m, b.prefix + ".channelwise.4.weight"), 4 * ch, x, ch, (int)rows, ch, 4 * ch);
+        g2.grn_gx = cx.f.grn_scale; g2.grn_part = cx.f.grn_gx; g2.grn_np = np; g2.grn_gamma = T(m, b.prefix + ".channelwise.2.gamma");
+        g2.a_shift = T(m, b.prefix + ".channelwise.2.beta");
+        g2.a_rows_per_sample = rps;
+        g2.ep.bias = T(m, b.prefix + ".channelwise.4.bias");
+        g2.ep.residual = x; g2.ep.ldr = ch;
+        if (b.emit_rowstat) g2.ep.rowstat_out = cx.f.rowstat;
+        if (b.fused_ts >= 0) {
+            g2.ep.ts = cx.f.ts + b.fused_ts; g2.ep.ts_stride = m->ts_total; g2.ep.rows_per_sample = rps;
+        }
+        RET_IF(launch_gemm(g2, cx.f.splitk, kSplitKBudget, cx.st));
+        return PAELLA_OK;
+    }
     if (rps % 16 == 0) {
         // GRN statistics ride on GEMM1's epilogue (per-16-row column sums of squares), then one tiny finalize launch
         g1.ep.sumsq_out = cx.f.grn_gx;
@@ -923,6 +945,23 @@ extern "C" int paella_test_gemm_prologue(const float* A, const float* W, float* 
     else if (mode == 2) { g.ln_stats = ln_stats; g.ln_nblk = K / 16; g.ln_eps = 1e-6f; }
     else if (mode != 0) { paella_set_error("prologue mode must be 0, 1 (scale / shift per sample) or 2 (LayerNorm from row statistics)"); return PAELLA_ERR_ARG; }
     return launch_gemm_cfg(g, tile_cfg, splitk, ws, ws_bytes, (hipStream_t)stream);
+}
+// test hook (test_hooks.h): the MLP pair of a ResBlock with GlobalResponseNorm finished inside the GEMMs (no finalize launch) -- the fused path of
+// run_mlp_block on caller-provided tensors: out[M, c] = GRN(gelu(h W1^T + b1)) W2^T, hidden [M, 4c], gx [M / rps, 4c], part [M / rps, 4c / 16]
+extern "C" int paella_test_mlp_grn_fused(const float* h, const float* W1, const float* b1, const float* gamma, const float* beta, const float* W2,
+                                         float* hidden, float* gx, float* part, float* out, int M, int c, int rps, void* ws, size_t ws_bytes, void* stream) {
+    const int tile = (rps % 16 == 0) ? gemm_grn_fused_tile(M, 4 * c, c, rps, true) : 0;
+    if (!tile) { paella_set_error("fused GRN not applicable (M=%d c=%d rows per sample=%d)", M, c, rps); return PAELLA_ERR_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    const int np = (4 * c / 32) * 2;
+    GemmArgs g1 = gemm_args(h, c, W1, c, hidden, 4 * c, M, 4 * c, c);
+    g1.ep.bias = b1; g1.ep.act = ACT_GELU;
+    g1.ep.grn_gx_out = gx; g1.ep.grn_part_out = part; g1.ep.grn_rps = rps; g1.ep.grn_np = np;
+    g1.force_ring_cfg = tile;
+    RET_IF(launch_gemm(g1, ws, ws_bytes, st));
+    GemmArgs g2 = gemm_args(hidden, 4 * c, W2, 4 * c, out, c, M, c, 4 * c);
+    g2.grn_gx = gx; g2.grn_part = part; g2.grn_np = np; g2.grn_gamma = gamma; g2.a_shift = beta; g2.a_rows_per_sample = rps;
+    return launch_gemm(g2, ws, ws_bytes, st);
 }
 extern "C" int paella_test_register_weight(const float* w, size_t numel, int on) {
     if (on) return gemm_register_weight(w, numel, 0);

@@ -18,6 +18,10 @@ int paella_test_attention_variant(int v);
  * squares) (LayerNorm folded into the consumer) */
 int paella_test_gemm_prologue(const float* A, const float* W, float* C, int M, int N, int K, int mode, const float* scale, const float* shift,
                               int rows_per_sample, const float* ln_stats, int tile_cfg, int splitk, void* ws, size_t ws_bytes, void* stream);
+/* out[M, c] = GRN(gelu(h W1^T + b1)) W2^T with GlobalResponseNorm finished inside the two GEMMs (the batch-1 path of a ResBlock's MLP: no finalize
+ * launch); scratch: hidden [M, 4c], gx [M / rps, 4c], part [M / rps, 4c / 16].  Fails when the shape is outside the fused path's domain. */
+int paella_test_mlp_grn_fused(const float* h, const float* W1, const float* b1, const float* gamma, const float* beta, const float* W2, float* hidden,
+                              float* gx, float* part, float* out, int M, int c, int rps, void* ws, size_t ws_bytes, void* stream);
 /* 0 = never use the direct-to-LDS (DMA) twins of the large GEMM tiles (A/B and parity checks); 1 = default */
 int paella_test_gemm_dma(int on);
 /* the LDS-DMA ring tile (config id 30..35) the launch heuristic uses for the skinny batch-1 shapes; 0 = the register-staged / 1-deep kernels (A/B) */

@@ -100,6 +100,41 @@ def test_gemm_operand_prologues_every_tile_config(lib, cfg, mode, splitk):
     np.testing.assert_allclose(C.cpu().numpy(), ref.numpy(), atol=2e-4, rtol=2e-5)
 
 
+@pytest.mark.parametrize("B,rps,c", [(2, 64, 1280), (2, 16, 1280), (1, 64, 64), (3, 16, 96), (5, 64, 32), (4, 16, 32)])
+def test_mlp_pair_with_grn_finished_inside_the_gemms(lib, B, rps, c):
+    """Batch-1 path of a ResBlock MLP (reference src/modules.py:30-40,49-53): Linear -> GELU -> GlobalResponseNorm -> Linear with NO launch for the
+    normalisation -- GEMM1's epilogue finishes Gx = ||g||_2 over each sample's rows (tiles cover whole samples) and leaves per-column-tile sums, GEMM2
+    derives mean_k Gx from them and applies gamma * (g * Gx / (mean + 1e-6)) + beta + g to its operand fragments.  Against fp64 torch math."""
+    M = B * rps
+    g = torch.Generator().manual_seed(B * 1000 + rps + c)
+    h = torch.randn(M, c, generator=g)
+    W1 = torch.randn(4 * c, c, generator=g) / c ** 0.5
+    b1 = 0.1 * torch.randn(4 * c, generator=g)
+    gamma, beta = 0.5 * torch.randn(4 * c, generator=g), 0.3 * torch.randn(4 * c, generator=g)
+    W2 = torch.randn(c, 4 * c, generator=g) / (4 * c) ** 0.5
+    hid = F.gelu(h.double() @ W1.double().t() + b1.double()).view(B, rps, 4 * c)
+    gx = hid.pow(2).sum(dim=1, keepdim=True).sqrt()
+    nx = gx / (gx.mean(dim=-1, keepdim=True) + 1e-6)
+    ref = ((gamma.double() * (hid * nx) + beta.double() + hid).view(M, 4 * c) @ W2.double().t()).float()
+    d = lambda t: t.cuda()
+    hd, W1d, b1d, gd, bd, W2d = d(h), d(W1), d(b1), d(gamma), d(beta), d(W2)
+    hidden = torch.full((M, 4 * c), float("nan"), device="cuda")
+    gxd = torch.full((B, 4 * c), float("nan"), device="cuda")
+    part = torch.full((B, 4 * c // 16), float("nan"), device="cuda")
+    out = torch.full((M, c), float("nan"), device="cuda")
+    ws = _lib.new_workspace(64 << 20, "cuda")
+    outs = []
+    for _ in range(2):
+        _check(lib, lib.paella_test_mlp_grn_fused(_p(hd), _p(W1d), _p(b1d), _p(gd), _p(bd), _p(W2d), _p(hidden), _p(gxd), _p(part), _p(out), M, c, rps,
+                                                  _p(ws), ws.numel(), _st()))
+        torch.cuda.synchronize()
+        outs.append(out.clone())
+    np.testing.assert_allclose(gxd.cpu().numpy(), gx.view(B, 4 * c).float().numpy(), rtol=2e-5, atol=1e-5)
+    np.testing.assert_allclose(part.sum(dim=1).cpu().numpy(), gx.view(B, 4 * c).sum(dim=1).float().numpy(), rtol=2e-5)
+    np.testing.assert_allclose(outs[0].cpu().numpy(), ref.numpy(), atol=2e-4 * max(1.0, float(ref.abs().max())), rtol=2e-5)
+    assert torch.equal(outs[0], outs[1])  # run-to-run bit-reproducible (fixed-order sums everywhere)
+
+
 @pytest.mark.parametrize("cfg", [10, 18])
 @pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("splitk", [1, -96])

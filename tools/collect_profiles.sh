@@ -3,7 +3,7 @@
 # Output: gpurun_out/<tag>_profiles/ -- kernel-trace summaries (batch 1, batch 32, BASELINE configs[2]), the HBM traffic files
 # bench.py reads (tools/pmc_traffic.py; stamped with the kernel-source hash), matrix-core busy counters.  Counters are collected
 # in passes of their own with --kernel-trace only (MI355X_MICROARCH.md, HBM / rocprofv3 section).
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/${TAG}_profiles
 mkdir -p $O
@@ -48,4 +48,12 @@ mfma() {  # name, command...
 mfma b1 $W_B1 --steps 2 --warmup 1 $COMMON
 mfma b32 $W_B32 --steps 1 --warmup 1 $COMMON
 mfma config3 $W_C3 --steps 1 --warmup 0 $COMMON
+# per-shape GEMM time inside the model (event-timed, eager): where the image's milliseconds go
+cd $R
+python tools/gemm_by_shape.py 2>&1 | grep -v amdgpu > $O/${TAG}_gemm_by_shape_b1.txt
+python tools/gemm_by_shape.py --batch 32 2>&1 | grep -v amdgpu > $O/${TAG}_gemm_by_shape_b32.txt
+python tools/gemm_by_shape.py --batch 64 --grid 64 --sample-steps 2 2>&1 | grep -v amdgpu > $O/${TAG}_gemm_by_shape_config3_2steps.txt
+# the parity report: every oracle / reference comparison with its near-tie counts printed (-s)
+{ echo "# python -m pytest tests -m gpu -q -s -k 'parity or vs_oracle or vs_reference or closed_loop or benchmarked or geometry or train_step or prompts_to_image or graph_sampler or reproduces or grn_finished'   (MI355X)"
+  python -m pytest tests -m gpu -q -s -p no:cacheprovider -k "parity or vs_oracle or vs_reference or closed_loop or benchmarked or geometry or train_step or prompts_to_image or graph_sampler or reproduces or grn_finished" 2>&1 | grep -v "amdgpu.ids" | grep -v "^\s*$"; } > $O/${TAG}_parity_report.txt
 ls -la $O

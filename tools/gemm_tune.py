@@ -97,8 +97,9 @@ def main():
         if a.big_only:
             variants = [(-1, 1)] + [(c, 1) for c in (0, 1, 2, 9, 10, 12, 14, 16, 18)]
         if M >= 4096:  # MFMA-bound: no split-K, few candidates, few iterations
-            variants = [(-1, 1)] + [(c, 1) for c in (0, 1, 2, 9, 10, 12, 14, 16, 18)] + \
-                       [(c, -G) for c in (2, 10, 14, 18) for G in (256, 512, 768, 1024)]
+            big = (0, 1, 2, 9, 10, 12, 14, 16, 18) + tuple(c for c in (32, 33, 34) if a.cfgs and str(c) in a.cfgs.split(","))
+            variants = [(-1, 1)] + [(c, 1) for c in big] + \
+                       [(c, -G) for c in (2, 10, 14, 18) + tuple(c for c in big if c >= 30) for G in (256, 512, 768, 1024)]
         for cfg, sk in variants:
             if sk > 1 and K // sk < 96:
                 continue
