@@ -53,7 +53,7 @@ shp = shp[:n * 5].reshape(n, 5)
 groups = collections.OrderedDict()
 for t, s in zip(us[:n], shp):
     groups.setdefault(tuple(int(v) for v in s), []).append(float(t))
-names = {0: "plain", 1: "GRN", 2: "LN", 3: "conv"}
+names = {0: "plain", 1: "GRN", 2: "LN", 3: "conv", 4: "GRNraw"}
 print("# python tools/gemm_by_shape.py --batch %d --grid %d --sample-steps %d: %d GEMM launches per image batch, event-timed, eager; per (M, N, K, prologue)" % (a.batch, a.grid, a.sample_steps, n))
 print("%-8s %-7s %-7s %-6s %6s %9s %9s %9s %7s" % ("M", "N", "K", "pro", "calls", "avg us", "min us", "total ms", "TF/s"))
 tot = 0.0
