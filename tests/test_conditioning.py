@@ -98,3 +98,35 @@ def test_clip_preprocess_matches_resize_normalize():
     assert C.clip_preprocess(torch.rand(1, 3, 224, 224)).shape == (1, 3, 224, 224)
     with pytest.raises(ValueError):
         C.clip_preprocess(torch.rand(3, 224, 224))
+
+
+def test_signature_mirrors_the_reference():
+    """Positional parameters of load_conditional_models = the reference's (src_distributed/utils.py:65).  The reference tree exists in the authoring
+    container only; elsewhere the expected names are the ones recorded here from it."""
+    import inspect
+    import re
+    expected = ["clip_model_name", "byt5_model_name", "vqgan_path", "device"]
+    ref = "/root/reference/src_distributed/utils.py"
+    if os.path.exists(ref):
+        m = re.search(r"def load_conditional_models\(([^)]*)\)", open(ref).read())
+        assert [a.strip() for a in m.group(1).split(",")] == expected
+    sig = inspect.signature(C.load_conditional_models)
+    positional = [p.name for p in sig.parameters.values() if p.kind == p.POSITIONAL_OR_KEYWORD]
+    assert positional == expected
+    assert all(p.kind == p.KEYWORD_ONLY for n, p in sig.parameters.items() if n not in expected)
+
+
+def test_spec_layout_equals_layout_from_tensors():
+    """cond_spec_layout (what a rank that never sees the tensors computes) == conditioning_layout (from the tensors): the one-collective path."""
+    from paella_amd.dist import cond_spec_layout, conditioning_layout
+
+    class M:
+        _cfg = dict(byt5_embd=24, clip_embd=10)
+    B = 3
+    for S, Su, clip, n_img in [(5, 1, True, 0), (0, None, True, 1), (7, 2, False, 2)]:
+        mk = lambda s, img: {"byt5": torch.zeros(B, s, 24), "clip": torch.zeros(B, 10) if clip else None,
+                             "clip_image": None if img == 0 else (torch.zeros(B, 10) if img == 1 else [torch.zeros(B, 10)] * img)}
+        want = conditioning_layout([mk(S, n_img), mk(S if Su is None else Su, n_img)])
+        got = cond_spec_layout(M(), B, S_byt5=S, S_byt5_uncond=Su, clip=clip, n_clip_image=n_img)
+        assert got[1] == want[1]
+        assert [[tuple(e) if not isinstance(e, tuple) else e for e in d] for d in got[0]] == [list(d) for d in want[0]]
