@@ -6,6 +6,7 @@ import torch
 import paella_amd
 from oracle import golden_configs as G
 from oracle import paella_oracle as O
+from paella_amd import synth
 from tests.helpers import weights_for
 
 pytestmark = pytest.mark.gpu
@@ -132,3 +133,29 @@ def test_inpaint_composition_vs_oracle(built_lib):
     assert enc_same
     assert same == osamp.numel()
     np.testing.assert_allclose(out.cpu().numpy(), oimg.numpy(), atol=1e-4)
+
+
+def test_codebook_search_lds_kernel_is_bit_identical_to_the_row_kernel(built_lib):
+    """VectorQuantize.forward (src/vqgan.py:94; stand-in semantics: argmin of |e|^2 + |x|^2 - 2 x.e, first minimum) on >= 4096 rows takes the kernel that keeps
+    the 8192 x 4 codebook resident in LDS; below it the wave-per-row kernel.  Same fp32 operation sequence per (row, code) pair and same tie-break, so a large call
+    must equal the concatenation of small calls bit for bit, and both must match a brute-force fp64 search except at near-ties (counted)."""
+    v = paella_amd.VQModel(**G.VQ_F8)
+    synth.randomize_(v, seed=0)
+    v = v.to(DEV)
+    g = torch.Generator().manual_seed(9)
+    rows = 4096 * 3 + 37                                   # ragged tail: the last 64-row chunk is partial
+    x = (torch.randn(rows, 4, generator=g) * 1.2).to(DEV)
+    x[5] = v.vquantizer.codebook.weight[123].detach()      # an exact hit
+    zq, _, idx = v.vquantizer.forward(x, get_losses=False)
+    small = torch.cat([v.vquantizer.forward(x[i:i + 1000], get_losses=False)[2] for i in range(0, rows, 1000)])
+    assert torch.equal(idx, small), "%d indices differ between the two kernels" % int((idx != small).sum())
+    assert int(idx[5]) == 123
+    cb = v.vquantizer.codebook.weight.detach().double().cpu()
+    d = (cb * cb).sum(1)[None, :] + (x.double().cpu() ** 2).sum(1)[:, None] - 2.0 * x.double().cpu() @ cb.t()
+    ref = d.argmin(1)
+    mism = ref != idx.cpu()
+    top = d.topk(2, dim=1, largest=False).values
+    near = (top[:, 1] - top[:, 0]) < 1e-5
+    print("LDS codebook search vs fp64 brute force: %d / %d indices differ, all at near-ties: %s" % (int(mism.sum()), rows, not bool((mism & ~near).any())))
+    assert not (mism & ~near).any()
+    assert torch.equal(zq, v.vquantizer.codebook.weight.detach()[idx])
