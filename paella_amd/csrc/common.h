@@ -122,6 +122,7 @@ struct GemmArgs {
     const float* ln_stats;
     int ln_nblk;
     float ln_eps;
+    const float* ln_wsum;      // [N]: sum_k W[n][k] -- the LayerNorm is folded into the epilogue as rstd * (acc - mean * wsum[n]) (gemm.hip: ln_row_stats)
     Epilogue ep;
     FusedTail ft;              // used by launch_gemm_tail only
     ConvGather cv;             // cv.enabled: A is an NHWC image gathered on the fly (lda unused, K == ntaps * C)

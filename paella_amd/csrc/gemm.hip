@@ -119,7 +119,7 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (TM * TN == 1 ? (RING == 3
     // Direct-to-LDS operands: one buffer_load_dwordx4 ... lds per wave and 8 tile rows writes 1 KiB at M0 + lane * 16, i.e. LDS stays
     // lane-linear; the XOR swizzle of the 16-byte slots is applied to the SOURCE address instead (lane l of a row fetches chunk
     // (l % 8) ^ (row % 8)).  Needs K % BK == 0 (no activation-side K-tail mask) -- the host picks the register-staged twin otherwise.
-    constexpr bool DMA_W = DMA || RING > 0, DMA_A = (DMA && APRO == 0) || RING > 0;
+    constexpr bool DMA_W = DMA || RING > 0, DMA_A = (DMA && (APRO == 0 || APRO == 2)) || RING > 0;  // (the LayerNorm is folded into the epilogue: the operand stays raw)
     static_assert(!DMA || (PD == 1 && BK == 32 && !TAIL && (BM * SL) % NT == 0 && (BN * SL) % NT == 0), "DMA variant: 1-deep, K step 32, whole passes");
     static_assert(RING == 0 || (RING >= 3 && RING <= 4 && !DMA && PD == 1 && BK == 32 && !TAIL && APRO != 3 && NW == 4 && (BM * SL) % NT == 0 && (BN * SL) % NT == 0),
                   "ring variant: 3 or 4 LDS stages, 4 waves, K step 32, whole passes, no implicit convolution");
@@ -203,7 +203,6 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (TM * TN == 1 ? (RING == 3
     unsigned aux_s_off = 0;  // ring + GRN prologue: this lane's source offset in the scale rows of the tile's samples (lane -> sample lane / 8, 16-byte chunk lane % 8)
     int cy[APRO == 3 ? LA : 1], cx[APRO == 3 ? LA : 1];  // implicit conv: top-left input coordinate of row i (aoff[i] = image base position)
     int ltap = 0, lc0 = 0;                                  // implicit conv: tap and channel offset of the load cursor's K step
-    float ln_mu[APRO == 2 ? LA : 1], ln_rs[APRO == 2 ? LA : 1];
     auto set_tile = [&](int tile) __attribute__((always_inline)) {
         int tile_m, tile_n;
         sk_tile_coords<(BM >= 64)>(p, tile, tile_m, tile_n);
@@ -251,29 +250,52 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (TM * TN == 1 ? (RING == 3
         ltap = (lkt * BK) / g.cv.C;
         lc0 = lkt * BK - ltap * g.cv.C;
     }
-    float fr_mu[(APRO == 2 && RING > 0) ? TM : 1], fr_rs[(APRO == 2 && RING > 0) ? TM : 1];  // ring: mean / rstd of this lane's fragment rows (set behind the first DMAs)
+    // LayerNorm-on-load, FOLDED INTO THE EPILOGUE: with mu / rstd the statistics of output row m,
+    //     sum_k ((a[m][k] - mu) * rstd) * W[n][k]  =  rstd * (sum_k a[m][k] * W[n][k]  -  mu * wsum[n]),      wsum[n] = sum_k W[n][k]  (precomputed, GemmArgs::ln_wsum)
+    // so the main loop multiplies the RAW operand (same loads, DMA and MFMA stream as a plain GEMM -- the per-unit (a - mu) * rstd on the fragments sat between the
+    // fragment reads and the MFMAs of every unit and cost 3-4 us per batch-1 launch, 10 % of the matrix-core rate at large batch) and the tile's finisher applies
+    // the two per-row scalars to the accumulators.  fr_mu / fr_rs: statistics of this lane's fragment rows (row r16 of 16-row block i), set behind the first operand
+    // fetches by ln_row_stats() below.  Computed ONCE: the host only launches this variant with ranges that never change tile_m.
+    float fr_mu[APRO == 2 ? TM : 1], fr_rs[APRO == 2 ? TM : 1];
     const int ln_tile0 = ltile;
-    if (APRO == 2 && RING == 0) {
-        // LayerNorm-on-load: combine the producer's per-16-column (sum, sumsq) partials of this thread's rows; the 8 lanes that
-        // share a row (tid & 7) split the blocks and xor-reduce.  fp64 for the final E[x^2] - mean^2.  Computed ONCE: the host
-        // only launches this variant with ranges that never change tile_m (tiles_m == 1, or every range inside one tile).
+    auto ln_row_stats = [&]() __attribute__((always_inline)) {
+        if (APRO != 2) return;
+        // the 4 lanes that hold one fragment row (kq = 0..3) split the producer's per-16-column (sum, sumsq) pairs as 16-byte chunks (two blocks each; a last odd
+        // block as a pair) and xor-reduce; fp64 for E[x^2] - mean^2
         int ln_tm, ln_tn;
-        sk_tile_coords<(BM >= 64)>(p, ltile, ln_tm, ln_tn);
-        const int m0 = ln_tm * BM;
+        sk_tile_coords<(BM >= 64)>(p, ln_tile0, ln_tm, ln_tn);
+        const int nch = g.ln_nblk >> 1;
 #pragma unroll
-        for (int i = 0; i < LA; ++i) {
-            const int gmc = min(m0 + ldrow + i * RP, g.M - 1);
-            const float* stp = g.ln_stats + (size_t)gmc * g.ln_nblk * 2;
-            double s = 0.0, q = 0.0;
-            for (int j = ldc4; j < g.ln_nblk; j += SL) { s += (double)stp[2 * j]; q += (double)stp[2 * j + 1]; }
-#pragma unroll
-            for (int o = 1; o < SL; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
-            const double mean = s / (double)g.K;
+        for (int i = 0; i < TM; ++i) {
+            const int gmc = min(ln_tm * BM + (wm * TM + i) * 16 + r16, g.M - 1);
+            const float* st0 = g.ln_stats + (size_t)gmc * g.ln_nblk * 2;
+            const bool vec = (((size_t)gmc * g.ln_nblk) & 1) == 0;  // 16-byte aligned row of pairs (always when ln_nblk is even)
+            double sm = 0.0, q = 0.0;
+            if (vec) {
+                const f32x4* stp = reinterpret_cast<const f32x4*>(st0);
+                int j = kq;
+                for (; j + 12 < nch; j += 16) {  // 4 independent loads in flight
+                    const f32x4 v0 = stp[j], v1 = stp[j + 4], v2 = stp[j + 8], v3 = stp[j + 12];
+                    sm += ((double)v0[0] + (double)v0[2]) + ((double)v1[0] + (double)v1[2]) + ((double)v2[0] + (double)v2[2]) + ((double)v3[0] + (double)v3[2]);
+                    q += ((double)v0[1] + (double)v0[3]) + ((double)v1[1] + (double)v1[3]) + ((double)v2[1] + (double)v2[3]) + ((double)v3[1] + (double)v3[3]);
+                }
+                for (; j < nch; j += 4) {
+                    const f32x4 v0 = stp[j];
+                    sm += (double)v0[0] + (double)v0[2];
+                    q += (double)v0[1] + (double)v0[3];
+                }
+                if ((g.ln_nblk & 1) && kq == 0) { sm += (double)st0[2 * (g.ln_nblk - 1)]; q += (double)st0[2 * (g.ln_nblk - 1) + 1]; }
+            } else {
+                for (int j = kq; j < g.ln_nblk; j += 4) { sm += (double)st0[2 * j]; q += (double)st0[2 * j + 1]; }
+            }
+            sm += __shfl_xor(sm, 16, 64); q += __shfl_xor(q, 16, 64);
+            sm += __shfl_xor(sm, 32, 64); q += __shfl_xor(q, 32, 64);
+            const double mean = sm / (double)g.K;
             const double var = q / (double)g.K - mean * mean;
-            ln_mu[i] = (float)mean;
-            ln_rs[i] = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + (double)g.ln_eps));
+            fr_mu[i] = (float)mean;
+            fr_rs[i] = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + (double)g.ln_eps));
         }
-    }
+    };
 
     auto load_unit = [&](Stage& r, int dma_slot) __attribute__((always_inline)) {  // loads the unit under the load cursor (DMA operands: into LDS stage dma_slot)
         float* dAs = smem + dma_slot * (RING > 0 ? STAGE_FLOATS : TILE_FLOATS) + (wave * (64 / SL)) * BK;  // this wave's first row group of the stage (wave-uniform -> M0)
@@ -334,7 +356,6 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (TM * TN == 1 ? (RING == 3
             const int row = ldrow + i * RP;
             f32x4 v = r.a[i];
             if (APRO == 1) v = v * r.s[i] + r.t;
-            if (APRO == 2) v = (v - ln_mu[i]) * ln_rs[i];
             if (!r.kok || (APRO == 3 && !r.ok[i])) v = f32x4{0.f, 0.f, 0.f, 0.f};
             if (LA * RP == BM || row < BM) *reinterpret_cast<f32x4*>(As + row * BK + ((ldc4 ^ (row & (SL - 1))) << 2)) = v;
         }
@@ -516,7 +537,9 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (TM * TN == 1 ? (RING == 3
                 const bool ok = m < g.M && nn < g.N;
                 f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (ok) {
-                    v = epilogue_apply(g.ep, g.N, m, nn, acc[i][j]);
+                    f32x4 a = acc[i][j];
+                    if (APRO == 2) a = (a - *reinterpret_cast<const f32x4*>(g.ln_wsum + nn) * fr_mu[i]) * fr_rs[i];  // the folded LayerNorm (see ln_row_stats)
+                    v = epilogue_apply(g.ep, g.N, m, nn, a);
                     epilogue_write(g.ep, g.C, g.ldc, m, nn, v);
                 }
                 if constexpr (RING > 0) {
@@ -760,12 +783,6 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (TM * TN == 1 ? (RING == 3
                     }
                 }
             }
-            if (APRO == 2) {
-#pragma unroll
-                for (int kk = 0; kk < KG; ++kk)
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) af[kk][i] = (af[kk][i] - fr_mu[i]) * fr_rs[i];
-            }
             if (TM * TN == 1) {
 #pragma unroll
                 for (int kk = 0; kk < KG; kk += 2)
@@ -800,37 +817,7 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (TM * TN == 1 ? (RING == 3
         constexpr int SIDE_DMAS = APRO == 4 ? 3 : 2;
 #pragma unroll
         for (int j = 0; j < RING - 1; ++j) fetch_ring(j);
-        if (APRO == 2) {
-            // LayerNorm-on-load statistics, computed while the first units are in flight: the 4 lanes that hold one fragment row (kq = 0..3)
-            // split the producer's per-16-column (sum, sumsq) pairs as 16-byte chunks (two blocks each) and xor-reduce; fp64 for E[x^2] - mean^2.
-            // Computed ONCE: the host only launches this variant with ranges that never change tile_m.
-            int ln_tm, ln_tn;
-            sk_tile_coords<(BM >= 64)>(p, ln_tile0, ln_tm, ln_tn);
-            const int nch = g.ln_nblk >> 1;  // 16-byte chunks per row (K % 32 == 0 -> ln_nblk even)
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int gmc = min(ln_tm * BM + (wm * TM + i) * 16 + r16, g.M - 1);
-                const f32x4* stp = reinterpret_cast<const f32x4*>(g.ln_stats + (size_t)gmc * g.ln_nblk * 2);
-                double sm = 0.0, q = 0.0;
-                int j = kq;
-                for (; j + 12 < nch; j += 16) {  // 4 independent loads in flight
-                    const f32x4 v0 = stp[j], v1 = stp[j + 4], v2 = stp[j + 8], v3 = stp[j + 12];
-                    sm += ((double)v0[0] + (double)v0[2]) + ((double)v1[0] + (double)v1[2]) + ((double)v2[0] + (double)v2[2]) + ((double)v3[0] + (double)v3[2]);
-                    q += ((double)v0[1] + (double)v0[3]) + ((double)v1[1] + (double)v1[3]) + ((double)v2[1] + (double)v2[3]) + ((double)v3[1] + (double)v3[3]);
-                }
-                for (; j < nch; j += 4) {
-                    const f32x4 v0 = stp[j];
-                    sm += (double)v0[0] + (double)v0[2];
-                    q += (double)v0[1] + (double)v0[3];
-                }
-                sm += __shfl_xor(sm, 16, 64); q += __shfl_xor(q, 16, 64);
-                sm += __shfl_xor(sm, 32, 64); q += __shfl_xor(q, 32, 64);
-                const double mean = sm / (double)g.K;
-                const double var = q / (double)g.K - mean * mean;
-                fr_mu[i] = (float)mean;
-                fr_rs[i] = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + (double)g.ln_eps));
-            }
-        }
+        ln_row_stats();  // while the first units are in flight
         int cs = 0, ls = RING - 1;
         int ctile = (int)(u0 / (unsigned)KT);
         int ckt = (int)(u0 - (unsigned)ctile * (unsigned)KT);
@@ -878,6 +865,7 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (TM * TN == 1 ? (RING == 3
     };
 #pragma unroll
     for (int j = 0; j < PD; ++j) fetch(R[j], 0);  // (DMA variants are 1-deep: unit 0 goes straight to LDS stage 0)
+    ln_row_stats();  // while the first units are in flight
     store_unit(R[0], 0);
     __syncthreads();
     if constexpr (PIPE) read_group(std::integral_constant<int, 0>{}, 0);
@@ -1134,10 +1122,12 @@ static void choose_config(int M, int N, int K, int apro, bool ring_allowed, int 
     if (T128 >= 1024) {
         // plain operands: 64x64 tiles, 4 independent workgroups per CU, grouped rasterisation (140 TFLOP/s on 32768x5120x1280);
         // with a prologue the 8-wave 128x128 tile stages the A operand half as often and ties or wins
-        if (apro == 0) { cfg = 18; G = T64; }
+        // (a LayerNorm-consuming GEMM multiplies the raw operand since round 3 -- the normalisation is folded into its epilogue -- and takes the plain rule:
+        // configs[2] 19.78 -> 20.41 images/s, profiles/r03_ring_rules_ab.txt)
+        if (apro == 0 || apro == 2) { cfg = 18; G = T64; }
         else { cfg = 10; G = T128; }
     } else if (macs >= 2.5e9) {
-        if (K <= 768 && T64 >= 1024) { cfg = 18; G = T64; }
+        if ((K <= 768 || apro == 2) && T64 >= 1024) { cfg = 18; G = T64; }  // (LayerNorm-folded GEMMs: one statistics pass per workgroup -> one tile per workgroup)
         else { cfg = 10; G = 256; }
     } else if (g_gemm_ring && ring_allowed && macs >= 1.2e9 && macs < 2.4e9 && T64 < 1024 && apro != 2) {
         // 1.2-2.4 GFLOP with few tiles (256x5120x1280, 1024x1280x1280, ...): the 32x32 ring tile on every resident slot is 8-12 % ahead of 64x64 tiles
@@ -1289,8 +1279,8 @@ static int launch_gemm_cfg_impl(const GemmArgs& g, int cfg, int splitk, void* ws
                          g.M, g.N, g.K, g.lda, g.ldw, g.ldc);
         return PAELLA_ERR_ARG;
     }
-    if ((g.ep.rowstat_out && (g.N & 15)) || (g.ln_stats && (g.a_scale || g.K != 16 * g.ln_nblk))) {
-        paella_set_error("gemm: row statistics need N %% 16 == 0 and K == 16 * ln_nblk");
+    if ((g.ep.rowstat_out && (g.N & 15)) || (g.ln_stats && (g.a_scale || g.K != 16 * g.ln_nblk || !g.ln_wsum))) {
+        paella_set_error("gemm: row statistics need N %% 16 == 0, K == 16 * ln_nblk and the weight's row sums (ln_wsum)");
         return PAELLA_ERR_ARG;
     }
     if (g.ep.store_mode == STORE_D2S && (g.ep.sC & 3)) {

@@ -75,6 +75,7 @@ struct paella_unet {
     // conditioning K|V of EVERY AttnBlock as one GEMM: kv_w [kv_total, c_cond] = rows of in_proj_weight[c:3c] . kv_mapper.1.weight per block
     // (composed at finalize), kv_b = in_proj_weight[c:3c] . kv_mapper.1.bias + in_proj_bias[c:3c]; kv_col[i] = first column of block i
     DevBuf kv_w, kv_b;
+    std::map<std::string, DevBuf> wsum;  // per LayerNorm-consuming weight (key of the weight tensor): its row sums, for the LayerNorm folded into the GEMM epilogue
     std::vector<int> kv_col;
     int kv_total = 0;
     int ts_total = 0;
@@ -269,6 +270,7 @@ extern "C" int paella_unet_create(const paella_unet_config* cfg, paella_unet** o
 extern "C" void paella_unet_destroy(paella_unet* m) {
     if (!m) return;
     for (auto& kv : m->t) if (kv.second.p) { gemm_unregister_weight(kv.second.p); (void)hipFree(kv.second.p); }
+    for (auto& kv : m->wsum) if (kv.second.p) (void)hipFree(kv.second.p);
     if (m->kv_w.p) { gemm_unregister_weight(m->kv_w.p); (void)hipFree(m->kv_w.p); }
     if (m->kv_b.p) (void)hipFree(m->kv_b.p);
     if (m->ts_w.p) (void)hipFree(m->ts_w.p);
@@ -379,6 +381,39 @@ extern "C" int paella_unet_finalize(paella_unet* m, void* stream) {
     for (auto& kv : m->specs) {
         auto it = m->t.find(kv.first);
         if (it == m->t.end() || !it->second.loaded) { paella_set_error("tensor '%s' was never loaded", kv.first.c_str()); return PAELLA_ERR_STATE; }
+    }
+    // Row sums of every weight whose GEMM consumes LayerNorm-from-statistics (the LayerNorm is folded into that GEMM's epilogue: gemm.hip, ln_row_stats):
+    // wsum[n] = sum_k W[n][k], as one M = 1 GEMM over a vector of ones per weight.
+    {
+        hipStream_t st = (hipStream_t)stream;
+        std::vector<std::pair<std::string, std::pair<int, int>>> todo;  // key -> (N, K) of the repacked matrix
+        auto want = [&](const Block& b) {
+            if (b.type == BT_ATTN && b.ln_from_stats) todo.push_back({b.prefix + ".attention.attn.in_proj_weight", {3 * b.c, b.c}});
+            if (b.type == BT_UP && b.ln_from_stats) todo.push_back({b.prefix + ".1.weight", {4 * b.c_to, b.c_from}});
+        };
+        for (const Block& b : m->down) want(b);
+        for (const Block& b : m->up) want(b);
+        if (m->clf_from_stats) todo.push_back({"clf.1.weight", {m->cfg.c_out * m->cfg.patch_size * m->cfg.patch_size, m->cfg.c_hidden[0]}});
+        if (!todo.empty()) {
+            int kmax = 0;
+            for (auto& t : todo) kmax = t.second.second > kmax ? t.second.second : kmax;
+            std::vector<float> ones_h((size_t)kmax, 1.0f);
+            DevBuf ones;
+            RET_IF(devbuf_alloc(ones, (size_t)kmax));
+            HIP_CHECK_RET(hipMemcpyAsync(ones.p, ones_h.data(), (size_t)kmax * sizeof(float), hipMemcpyHostToDevice, st));
+            int rc = PAELLA_OK;
+            for (auto& t : todo) {
+                DevBuf& dst = m->wsum[t.first];
+                rc = devbuf_alloc(dst, (size_t)t.second.first);
+                if (rc != PAELLA_OK) break;
+                GemmArgs g = gemm_args(ones.p, t.second.second, T(m, t.first), t.second.second, dst.p, t.second.first, 1, t.second.first, t.second.second);
+                rc = launch_gemm_cfg(g, 5, 1, nullptr, 0, st);  // explicit fp32 tile, one tile per workgroup (no workspace needed)
+                if (rc != PAELLA_OK) break;
+            }
+            if (hipStreamSynchronize(st) != hipSuccess && rc == PAELLA_OK) { paella_set_error("finalize: stream error while summing weight rows"); rc = PAELLA_ERR_HIP; }
+            (void)hipFree(ones.p);
+            if (rc != PAELLA_OK) return rc;
+        }
     }
     // Compose the conditioning projections (reference src/modules.py:72-77: kv = kv_mapper(c_embed), then nn.MultiheadAttention's K / V in-projection
     // of those rows): K|V = (silu(c) . Wkv^T + bkv) . Win[c:3c]^T + bin[c:3c] = silu(c) . (Win[c:3c] . Wkv)^T + (Win[c:3c] . bkv + bin[c:3c]).
@@ -665,6 +700,7 @@ static int run_attn_block(FwdCtx& cx, const Block& b, float* x, int h, int w) {
     GemmArgs gq = gemm_args(cx.f.h, ch, T(m, b.prefix + ".attention.attn.in_proj_weight"), ch, cx.f.g, nq, (int)rows, nq, ch);
     if (b.ln_from_stats) {  // LayerNorm folded into the in-projection's operand load (statistics from the producer's epilogue)
         gq.A = x; gq.ln_stats = cx.f.rowstat; gq.ln_nblk = ch / 16; gq.ln_eps = 1e-6f;
+        gq.ln_wsum = m->wsum.at(b.prefix + ".attention.attn.in_proj_weight").p;
     } else {
         RET_IF(launch_layernorm(x, cx.f.h, rows, ch, 1e-6f, 1.f, 0.f, 0, 0, 0, cx.st));
     }
@@ -803,7 +839,7 @@ static int unet_forward_impl(paella_unet* m, const int64_t* tokens, const float*
                 const int64_t rows_in = (int64_t)B * h * w;
                 float* dst = f.xu[b.level - 1];
                 GemmArgs g = gemm_args(f.h, b.c_from, T(m, b.prefix + ".1.weight"), b.c_from, dst, b.c_to, (int)rows_in, 4 * b.c_to, b.c_from);
-                if (b.ln_from_stats) { g.A = x; g.ln_stats = f.rowstat; g.ln_nblk = b.c_from / 16; g.ln_eps = 1e-6f; }
+                if (b.ln_from_stats) { g.A = x; g.ln_stats = f.rowstat; g.ln_nblk = b.c_from / 16; g.ln_eps = 1e-6f; g.ln_wsum = m->wsum.at(b.prefix + ".1.weight").p; }
                 else RET_IF(launch_layernorm(x, f.h, rows_in, b.c_from, 1e-6f, 1.f, 0.f, 0, 0, 0, st));
                 g.ep.bias = T(m, b.prefix + ".1.bias");
                 g.ep.store_mode = STORE_D2S; g.ep.sH = h; g.ep.sW = w; g.ep.sC = b.c_to; g.ep.n_seg_x = 2;
@@ -826,7 +862,7 @@ static int unet_forward_impl(paella_unet* m, const int64_t* tokens, const float*
         const int p2 = p * p;
         const int64_t n0 = (int64_t)B * h0 * w0;  // full batch again
         GemmArgs g = gemm_args(f.h, c.c_hidden[0], T(m, "clf.1.weight"), c.c_hidden[0], f.g, c.c_out, (int)n0, c.c_out * p2, c.c_hidden[0]);
-        if (m->clf_from_stats) { g.A = x; g.ln_stats = f.rowstat; g.ln_nblk = c.c_hidden[0] / 16; g.ln_eps = 1e-6f; }
+        if (m->clf_from_stats) { g.A = x; g.ln_stats = f.rowstat; g.ln_nblk = c.c_hidden[0] / 16; g.ln_eps = 1e-6f; g.ln_wsum = m->wsum.at("clf.1.weight").p; }
         else RET_IF(launch_layernorm(x, f.h, n0, c.c_hidden[0], 1e-6f, 1.f, 0.f, 0, 0, 0, st));
         g.ep.bias = T(m, "clf.1.bias");
         if (p == 2) { g.ep.store_mode = STORE_D2S; g.ep.sH = h0; g.ep.sW = w0; g.ep.sC = c.c_out; g.ep.n_seg_x = 2; }
@@ -942,7 +978,21 @@ extern "C" int paella_test_gemm_prologue(const float* A, const float* W, float* 
                                          size_t ws_bytes, void* stream) {
     GemmArgs g = gemm_args(A, K, W, K, C, N, M, N, K);
     if (mode == 1) { g.a_scale = scale; g.a_shift = shift; g.a_rows_per_sample = rows_per_sample; }
-    else if (mode == 2) { g.ln_stats = ln_stats; g.ln_nblk = K / 16; g.ln_eps = 1e-6f; }
+    else if (mode == 2) {
+        g.ln_stats = ln_stats; g.ln_nblk = K / 16; g.ln_eps = 1e-6f;
+        {   // the weight's row sums, summed here into a cached scratch buffer (one extra M = 1 launch per call: timing loops over this hook include it)
+            static DevBuf ones, wsum;
+            if (ones.n < (size_t)K) {
+                std::vector<float> h((size_t)K, 1.0f);
+                RET_IF(devbuf_alloc(ones, (size_t)K));
+                HIP_CHECK_RET(hipMemcpy(ones.p, h.data(), (size_t)K * sizeof(float), hipMemcpyHostToDevice));
+            }
+            if (wsum.n < (size_t)N) RET_IF(devbuf_alloc(wsum, (size_t)N));
+            GemmArgs gs = gemm_args(ones.p, K, W, K, wsum.p, N, 1, N, K);
+            RET_IF(launch_gemm_cfg(gs, 5, 1, nullptr, 0, (hipStream_t)stream));
+            g.ln_wsum = wsum.p;
+        }
+    }
     else if (mode != 0) { paella_set_error("prologue mode must be 0, 1 (scale / shift per sample) or 2 (LayerNorm from row statistics)"); return PAELLA_ERR_ARG; }
     return launch_gemm_cfg(g, tile_cfg, splitk, ws, ws_bytes, (hipStream_t)stream);
 }

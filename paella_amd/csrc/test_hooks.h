@@ -15,7 +15,7 @@ int paella_test_launch_chain(float* buf, int n_elems, int blocks, int n_launches
 int paella_test_attention_variant(int v);
 /* C = prologue(A) . W^T with an explicit tile config / workgroup count (as paella_op_gemm): mode 1: a' = a * scale[row / rows_per_sample][k] +
  * shift[k] (the GRN apply of the MLP's second GEMM); mode 2: a' = (a - mean) * rstd from ln_stats [M, K/16, 2] = per 16-column block (sum, sum of
- * squares) (LayerNorm folded into the consumer) */
+ * squares) (LayerNorm folded into the consumer's EPILOGUE; the hook sums W's rows itself with one extra M = 1 launch per call) */
 int paella_test_gemm_prologue(const float* A, const float* W, float* C, int M, int N, int K, int mode, const float* scale, const float* shift,
                               int rows_per_sample, const float* ln_stats, int tile_cfg, int splitk, void* ws, size_t ws_bytes, void* stream);
 /* out[M, c] = GRN(gelu(h W1^T + b1)) W2^T with GlobalResponseNorm finished inside the two GEMMs (the batch-1 path of a ResBlock's MLP: no finalize

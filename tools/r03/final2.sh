@@ -5,7 +5,7 @@ O=$R/gpurun_out/r03_final2
 mkdir -p $O
 cd $R
 python -c "import __graft_entry__ as g; g.build(); g.smoke()" 2>&1 | tail -1
-python -m pytest tests/test_gpu_sample.py -q -x -p no:cacheprovider -k "fused_head or benchmarked" 2>&1 | tail -1
+python -m pytest tests/test_gpu_sample.py tests/test_gpu_ops.py -q -x -p no:cacheprovider -k "fused_head or benchmarked or prologues or direct_to_lds" 2>&1 | tail -1
 cd /tmp && export TMPDIR=/tmp
 COMMON="--no-cpu-baseline --no-extra --no-graph"
 traffic() {  # name, batch grid sample_steps, command...
