@@ -31,11 +31,13 @@ CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
 CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
 
 
-def load_checkpoint(module, path, map_location=None, key="state_dict", strict=True):
+def load_checkpoint(module, path, map_location=None, key="state_dict", strict=True, weights_only=True):
     """`module.load_state_dict(torch.load(path)['state_dict'])` (src/utils.py:26, src/train.py:40, src_distributed/utils.py:67).  Accepts the
     reference's checkpoint files unchanged: a dict with the weights under `key`; a bare state dict is accepted too, and a leading
-    'module.' (a DistributedDataParallel wrapper saved whole) is stripped.  Returns the checkpoint's other entries (iter, optimizer state, ...)."""
-    ckpt = torch.load(path, map_location=map_location if map_location is not None else "cpu", weights_only=False)
+    'module.' (a DistributedDataParallel wrapper saved whole) is stripped.  Returns the checkpoint's other entries (iter, optimizer state, ...).
+    weights_only=True (default) restricts unpickling to tensors / plain containers -- what the reference's checkpoints hold (state dicts, optimizer and
+    scaler state, counters, strings); pass False only for a trusted file that pickles other objects."""
+    ckpt = torch.load(path, map_location=map_location if map_location is not None else "cpu", weights_only=weights_only)
     sd = ckpt[key] if isinstance(ckpt, dict) and key in ckpt else ckpt
     if not isinstance(sd, dict) or not sd:
         raise ValueError("%s holds no state dict under %r" % (path, key))
