@@ -12,8 +12,8 @@ Mirrors
 The encoders are EXTERNAL frozen models, not part of the hot path: they run through `transformers` as plain torch modules
 on whatever device they are put on; only what they feed -- the denoiser and the VQGAN -- is this package's HIP code.  Differences from the
 reference, all forced by what is installable here and stated where they bite:
-  * CLIP comes from `transformers` (`CLIPModel`), not `open_clip` (absent, no network): `('ViT-H-14', 'laion2b_s32b_b79k')` maps to the
-    Hugging Face export of the SAME checkpoint, `laion/CLIP-ViT-H-14-laion2B-s32B-b79K`; the wrapper exposes open_clip's `encode_text` /
+  * CLIP comes from `open_clip` when that package is importable (the reference's own call sequence) and otherwise -- as in this image, where it is
+    absent and there is no network -- from `transformers` (`CLIPModel`): `('ViT-H-14', 'laion2b_s32b_b79k')` maps to the Hugging Face export of the SAME checkpoint, `laion/CLIP-ViT-H-14-laion2B-s32B-b79K`; the wrapper exposes open_clip's `encode_text` /
     `encode_image` (projected, un-normalised features, as open_clip returns by default);
   * `torchvision` is absent: `clip_preprocess` is the same Resize(224, bicubic, antialias) + Normalize written with torch ops;
   * offline, `from_pretrained` can only succeed from a local directory / cache.  `encoders="config"` builds the encoders from configs with
@@ -156,6 +156,15 @@ def load_conditional_models(clip_model_name, byt5_model_name, vqgan_path, device
     if clip_model_name is None:
         return vqgan, (byt5_tokenizer, byt5)
 
+    if encoders == "pretrained" and not isinstance(clip_model_name, str):
+        try:  # the reference's own loader when it is installed (it is not in this image): src_distributed/utils.py:73-75, verbatim call sequence
+            import open_clip
+        except ImportError:
+            open_clip = None
+        if open_clip is not None:
+            clip_model, _, _ = open_clip.create_model_and_transforms(clip_model_name[0], pretrained=clip_model_name[1], device=device)
+            clip_model = _freeze(clip_model, device)
+            return vqgan, (open_clip.get_tokenizer(clip_model_name[0]), clip_model, clip_preprocess), (byt5_tokenizer, byt5)
     if encoders == "pretrained":
         repo = OPEN_CLIP_TO_HF.get(tuple(clip_model_name), None) if not isinstance(clip_model_name, str) else clip_model_name
         if repo is None:
