@@ -70,6 +70,9 @@ def parse():
     ap.add_argument("--no-extra", action="store_true", help="skip the throughput-batch runs (batch 32 at configs[1], BASELINE configs[2])")
     ap.add_argument("--gemm", default="fp32", choices=["fp32", "bf16"],
                     help="fp32 = the exact path (the headline); bf16 = OPT-IN fast mode outside the parity contract (bf16 MFMA operands, fp32 accumulate)")
+    ap.add_argument("--hook", action="append", default=[], metavar="NAME=INT",
+                    help="A/B only: call the library's test hook paella_test_NAME(INT) before building the model (paella_amd/csrc/test_hooks.h); "
+                         "recorded in the output line as `test_hooks` -- a line with hooks set is not the product configuration")
     ap.add_argument("--force-dist", action="store_true", help="take the torch.distributed (RCCL) path even at world size 1 (launch under torchrun)")
     return ap.parse_args()
 
@@ -240,6 +243,11 @@ def main():
     from paella_amd.dist import broadcast_conditioning, conditioning_layout, shard_bounds, shard_inputs
     lib = _lib.load()  # fails loudly if the HIP library is missing
     paella_amd.set_gemm_precision(a.gemm)
+    hooks = {}
+    for h in a.hook:
+        name, val = h.split("=")
+        _lib.check(getattr(lib, "paella_test_" + name)(int(val)))
+        hooks[name] = int(val)
 
     mcfg, vcfg = MODELS[a.model], VQ[a.model]
     model = paella_amd.Paella(**mcfg)
@@ -385,6 +393,8 @@ def main():
                        "collective_backend": (dist.get_backend() + " (RCCL)" if distributed else None)},
             "roofline": roof, "cpu_baseline": cpu, "throughput": throughput,
         }
+        if hooks:
+            line["test_hooks"] = hooks  # A/B run: NOT the product configuration
         print(json.dumps(line), flush=True)
     if distributed:
         dist.destroy_process_group()

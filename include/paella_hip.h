@@ -45,6 +45,9 @@ extern "C" {
 
 int paella_abi_version(void);
 const char* paella_last_error(void);
+/* Hash of the kernel sources this library was built from (paella_amd/_stamp.py); the Python binding refuses a library whose stamp differs
+ * from the sources next to it. */
+const char* paella_source_stamp(void);
 
 /* Zeroes the header (paella_workspace_header_bytes() bytes) of a freshly allocated workspace; required once before the
  * workspace is first passed to any entry point below.  Enqueued on `stream`, no host synchronisation. */

@@ -38,6 +38,7 @@ class VqganConfig(Structure):
 SIGNATURES = {
     "paella_abi_version": (c_int, []),
     "paella_last_error": (c_char_p, []),
+    "paella_source_stamp": (c_char_p, []),
     "paella_workspace_init": (c_int, [c_void_p, c_size_t, c_void_p]),
     "paella_workspace_header_bytes": (c_size_t, []),
     "paella_unet_create": (c_int, [POINTER(UnetConfig), POINTER(c_void_p)]),
@@ -100,6 +101,10 @@ TEST_HOOKS = {
     "paella_test_gemm_dma": (c_int, [c_int]),
     "paella_test_gemm_raster": (c_int, [c_int]),
     "paella_test_gemm_ring": (c_int, [c_int]),
+    "paella_test_gemm_big": (c_int, [c_int]),
+    "paella_test_gemm_big_stagger": (c_int, [c_int]),
+    "paella_test_grn_fuse": (c_int, [c_int]),
+    "paella_test_ln_fold_ratio": (c_int, [c_float]),
     "paella_test_mlp_grn_fused": (c_int, [c_void_p] * 10 + [c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "paella_test_gemm_tail_tile": (c_int, [c_int]),
     "paella_test_tail_scores": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, c_float, c_float, c_uint64, c_uint64, c_int64, c_void_p, c_void_p]),
@@ -131,6 +136,11 @@ def load():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch, let it propagate loudly
         fn.restype = res
         fn.argtypes = args
+    from ._stamp import source_stamp
+    built, here = lib.paella_source_stamp().decode(), source_stamp()
+    if built != here:
+        raise PaellaHipError("libpaella_hip.so was built from other sources (library stamp %s, sources in the tree %s): rebuild with "
+                             "`python -m paella_amd.build`; a stale library is never used silently" % (built, here))
     if lib.paella_abi_version() != ABI_VERSION:
         raise PaellaHipError("libpaella_hip.so ABI %d != binding ABI %d" % (lib.paella_abi_version(), ABI_VERSION))
     _lib = lib

@@ -1,0 +1,23 @@
+"""Hash of the kernel sources a libpaella_hip.so was built from.
+
+build.py embeds it in the library (`paella_source_stamp()`); `_lib.load()` recomputes it from the sources in the tree and REFUSES a
+library built from other sources -- a stale .so next to newer sources (reset mtimes, a partial copy) must not be benchmarked silently."""
+import hashlib
+import os
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+SOURCES = ["gemm.hip", "gemm_bf16.hip", "elementwise.hip", "dwconv.hip", "attention.hip", "tail.hip", "vqgan.hip", "model.hip", "vqmodel.hip"]
+HEADERS = ["common.h", "internal.h", "gemm_device.h", "philox.h", "test_hooks.h", os.path.join("..", "..", "include", "paella_hip.h")]
+
+
+def source_files():
+    return [os.path.normpath(os.path.join(CSRC, f)) for f in SOURCES + HEADERS]
+
+
+def source_stamp():
+    h = hashlib.sha256()
+    for path in source_files():
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:32]

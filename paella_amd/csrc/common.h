@@ -55,7 +55,7 @@ struct Epilogue {
     int sH, sW, sC;         // STORE_D2S / PIXSHUF: source grid (rows m=(b,y,x)), channels per segment
     int py, px;             // STORE_D2S: extra output offset (transposed-conv phase)
     int n_seg_x;            // STORE_D2S: segments along n are (dy,dx) with dx in [0,n_seg_x); 2 for k2s2, 1 for a phase
-    float* rowstat_out;     // optional [M, N/16, 2]: per row and 16-column block, (sum, sum of squares) of the stored values (LayerNorm-on-load)
+    float* rowstat_out;     // optional [M, N/16, 2]: per row and 16-column block, (sum, centred sum of squares M2) of the stored values (LayerNorm-on-load; gemm_device.h)
     float* sumsq_out;       // optional [ceil(M/16), N]: per 16-row group, column sums of the stored values squared (GRN)
     // optional (ring tiles whose rows cover whole samples: grn_rps == 16 or == the tile height): GlobalResponseNorm's Gx finished IN this epilogue --
     // grn_gx_out [samples, N] = sqrt(sum over the sample's rows of value^2) and grn_part_out [samples, grn_np] = per (column tile, wave column) sums of
@@ -118,10 +118,11 @@ struct GemmArgs {
     int grn_np;
     int force_ring_cfg;        // > 0: the launch heuristic uses this ring tile for a skinny problem (the producer of grn_gx must cover whole samples)
     // or (exclusive with a_scale) LayerNorm of the A rows from producer statistics: a' = (a - mean[m]) * rstd[m],
-    // mean/var combined from ln_stats [M, ln_nblk, 2] (Epilogue::rowstat_out of the GEMM that produced A), K == 16*ln_nblk
+    // mean/var combined (parallel-variance formula, fp64) from ln_stats [M, ln_nblk, 2] = (sum, centred M2) per block (Epilogue::rowstat_out of the GEMM that produced A), K == 16*ln_nblk
     const float* ln_stats;
     int ln_nblk;
     float ln_eps;
+    float ln_fold_ratio;       // 16-row blocks with |mean| * rstd above this normalise their operand fragments instead of using the fold (set by launch_gemm_cfg)
     const float* ln_wsum;      // [N]: sum_k W[n][k] -- the LayerNorm is folded into the epilogue as rstd * (acc - mean * wsum[n]) (gemm.hip: ln_row_stats)
     Epilogue ep;
     FusedTail ft;              // used by launch_gemm_tail only

@@ -32,6 +32,7 @@
 #include "philox.h"
 #include <stdio.h>
 #include <stdlib.h>
+#include "test_hooks.h"
 #include <atomic>
 #include <mutex>
 #include <type_traits>
@@ -44,6 +45,7 @@ struct SkPlan {
     int KT;                // K steps per tile
     unsigned U;            // tiles_m * tiles_n * KT work units
     unsigned q, r;         // U = G*q + r: workgroup g owns [g*q + min(g, r), +q + (g < r)) -- 32-bit arithmetic only on the device
+    int stagger;           // 256x128 tile: which waves run their non-MFMA phase late (0 none, 1 waves >= 4, 2 odd waves)
     int gm;                // tile rasterisation: groups of gm tile rows, m fastest inside a group, then n, then the next group.
                            // gm >= tiles_m = plain m-fastest order.  The ~32 tiles that run together on an XCD then form a gm x (32 / gm)
                            // block that shares gm activation panels and 32 / gm weight panels in that XCD's L2 instead of 32 + 1.
@@ -101,9 +103,14 @@ template <int WM, int WN, int TM, int TN, int PD, int APRO, bool TAIL = false, i
 // GRN-prologue variant (two more staged operands per unit): forced under 96 registers it spills inside the unit loop (measured
 // 33 us instead of 25 for 128x1280x5120), so it runs 4 workgroups per CU and the heuristic gives it at most 1024 workgroups.
 // The 8-wave 128x64 tiles fit 128 VGPRs without spilling when asked to (126 / 128): two workgroups per CU instead of one.
-__global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (TM * TN == 1 ? (RING == 3 ? 5 : 4) : (TM * TN == 2 ? 4 : 3))
+// BIG = ring variant on 8 waves with 64x64 wave tiles (tile id 36: 256x128): the throughput-regime kernel.  One workgroup per CU, three 48 KiB LDS
+// stages (two K steps in flight), fragments read one 16-wide k group ahead of the MFMAs that consume them -- including across the K-step barrier -- so
+// neither a ds_read latency nor a store phase ever sits in front of an idle matrix core; the GRN prologue is applied to the fragments from a side
+// stage that holds the scale rows of up to 16 consecutive samples.
+__global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (WM * WN == 8 ? 1 : TM * TN == 1 ? (RING == 3 ? 5 : 4) : (TM * TN == 2 ? 4 : 3))
                                            : (TAIL && WM * WN == 8 && TM * TN == 4) ? 4  // fused head + tail on 128x64 tiles: TWO+ workgroups per CU, one's Philox / log epilogue overlaps another's main loop
                                            : (WM == 2 && WN == 2 && TM * TN == 1 && PD == 2 && BK == 32 && APRO != 1) ? 5
+                                           : (DMA && WM * WN == 4 && TM * TN == 16) ? 2  // 128x128 on 4 waves, direct-to-LDS: two independent workgroups per CU (64 KiB of LDS each)
                                            : ((WM * WN == 8 && WM * TM == 8 && WN * TN == 4 && PD == 2 && BK == 32 && APRO == 0 && !TAIL) ? 4 : 1)) void gemm_nt_kernel(GemmArgs g, SkPlan p, float* __restrict__ slabs,
                                                                unsigned* __restrict__ tickets, unsigned slab_bytes) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
@@ -121,14 +128,18 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (TM * TN == 1 ? (RING == 3
     // (l % 8) ^ (row % 8)).  Needs K % BK == 0 (no activation-side K-tail mask) -- the host picks the register-staged twin otherwise.
     constexpr bool DMA_W = DMA || RING > 0, DMA_A = (DMA && (APRO == 0 || APRO == 2)) || RING > 0;  // (the LayerNorm is folded into the epilogue: the operand stays raw)
     static_assert(!DMA || (PD == 1 && BK == 32 && !TAIL && (BM * SL) % NT == 0 && (BN * SL) % NT == 0), "DMA variant: 1-deep, K step 32, whole passes");
-    static_assert(RING == 0 || (RING >= 3 && RING <= 4 && !DMA && PD == 1 && BK == 32 && !TAIL && APRO != 3 && NW == 4 && (BM * SL) % NT == 0 && (BN * SL) % NT == 0),
-                  "ring variant: 3 or 4 LDS stages, 4 waves, K step 32, whole passes, no implicit convolution");
+    static_assert(RING == 0 || (RING >= 3 && RING <= 4 && !DMA && PD == 1 && BK == 32 && !TAIL && APRO != 3 && (NW == 4 || (TM == 4 && TN == 4 && RING == 3)) && (BM * SL) % NT == 0 && (BN * SL) % NT == 0),
+                  "ring variant: 3 or 4 LDS stages, 4 waves (or 8 waves of 64x64 wave tiles), K step 32, whole passes, no implicit convolution");
     static_assert(APRO != 4 || RING > 0, "the GRN-from-raw-statistics prologue exists on ring tiles only");
+    constexpr bool BIG = RING > 0 && NW == 8;
+    static_assert(!BIG || APRO != 4, "the 8-wave ring tile has no GRN-from-raw-statistics prologue");
     constexpr bool GRN_SIDE = RING > 0 && (APRO == 1 || APRO == 4);
     // ring stage = the A and W tiles + (GRN prologues) a side stage: 8 copies of shift[k0 .. k0 + 32) | scale rows of 8 consecutive samples (APRO 1), or
     // (APRO 4, exec-masked DMAs that move 128 bytes each) shift[k0 .. +32) | gamma[k0 .. +32) | gx rows of 8 consecutive samples
-    constexpr int AUX_FLOATS = (RING > 0 && APRO == 1) ? 512 : ((RING > 0 && APRO == 4) ? 320 : 0);
-    constexpr int GRN_SCR = RING > 0 ? WM * WN * TN * 16 : 0;  // epilogue scratch: per-wave column sums of squares when a sample spans several waves' rows
+    // (BIG: shift[k0 .. k0 + 32) once (an exec-masked 128-byte DMA) at float 0 | scale rows of 16 consecutive samples from float 64)
+    constexpr int AUX_FLOATS = (BIG && APRO == 1) ? 576 : (RING > 0 && APRO == 1) ? 512 : ((RING > 0 && APRO == 4) ? 320 : 0);
+    constexpr bool GRN_FIN = RING > 0 && !BIG;  // tiles whose epilogue can finish GlobalResponseNorm's Gx (batch-1 regime only)
+    constexpr int GRN_SCR = GRN_FIN ? WM * WN * TN * 16 : 0;  // epilogue scratch: per-wave column sums of squares when a sample spans several waves' rows
     constexpr int STAGE_FLOATS = TILE_FLOATS + AUX_FLOATS;
     constexpr int FLAG_OFF = RING > 0 ? RING * STAGE_FLOATS : 2 * TILE_FLOATS;  // 16 floats for the ticket broadcast behind the stages
     // one LDS object: two tile stages + 16 floats for the ticket broadcast (the NEXT unit's tile is already staged when a
@@ -200,6 +211,7 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (TM * TN == 1 ? (RING == 3
     const __amdgpu_buffer_rsrc_t rsrcT = rsrc_of((APRO == 1 || APRO == 4) ? g.a_shift : g.A, (APRO == 1 || APRO == 4) ? (size_t)g.K * sizeof(float) : 16);
     const __amdgpu_buffer_rsrc_t rsrcG = rsrc_of(APRO == 4 ? g.grn_gamma : g.A, APRO == 4 ? (size_t)g.K * sizeof(float) : 16);
     unsigned aoff[LA], soff[APRO == 1 ? LA : 1], boff[LB];
+    unsigned aux_s_off2 = 0;  // (BIG: the same for samples 8..15 of the tile)
     unsigned aux_s_off = 0;  // ring + GRN prologue: this lane's source offset in the scale rows of the tile's samples (lane -> sample lane / 8, 16-byte chunk lane % 8)
     int cy[APRO == 3 ? LA : 1], cx[APRO == 3 ? LA : 1];  // implicit conv: top-left input coordinate of row i (aoff[i] = image base position)
     int ltap = 0, lc0 = 0;                                  // implicit conv: tap and channel offset of the load cursor's K step
@@ -241,6 +253,7 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (TM * TN == 1 ? (RING == 3
         if (GRN_SIDE) {
             const int last = (g.M - 1) / g.a_rows_per_sample - smp0;  // clamp: rows past the last sample re-read it (never used)
             aux_s_off = ((unsigned)min(lane_k >> 3, last) * (unsigned)g.K + (unsigned)((lane_k & 7) * 4)) * 4u;
+            if (BIG) aux_s_off2 = ((unsigned)min(8 + (lane_k >> 3), last) * (unsigned)g.K + (unsigned)((lane_k & 7) * 4)) * 4u;
         }
 #pragma unroll
         for (int i = 0; i < LB; ++i) boff[i] = ((unsigned)(min(n0 + ldrow + i * RP, g.N - 1) - n0) * (unsigned)g.ldw + (unsigned)((DMA_W ? (ldc4 ^ (ldrow & (SL - 1))) : ldc4) * 4)) * 4u;
@@ -257,45 +270,59 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (TM * TN == 1 ? (RING == 3
     // the two per-row scalars to the accumulators.  fr_mu / fr_rs: statistics of this lane's fragment rows (row r16 of 16-row block i), set behind the first operand
     // fetches by ln_row_stats() below.  Computed ONCE: the host only launches this variant with ranges that never change tile_m.
     float fr_mu[APRO == 2 ? TM : 1], fr_rs[APRO == 2 ? TM : 1];
+    // the fold cancels when |mu| >> std (gemm_device.h: kLnFoldMaxRatio): such 16-row blocks normalise their operand FRAGMENTS instead (ln_fix) and skip the fold
+    float fr_mu_lo[APRO == 2 ? TM : 1];  // mean - (float)mean: the operand-side form subtracts the mean in two pieces (an fp32 mean alone is off by eps * |mean|, i.e. eps * ratio in units of std)
+    bool ln_dir[APRO == 2 ? TM : 1];
+    bool ln_any = false;
     const int ln_tile0 = ltile;
     auto ln_row_stats = [&]() __attribute__((always_inline)) {
-        if (APRO != 2) return;
-        // the 4 lanes that hold one fragment row (kq = 0..3) split the producer's per-16-column (sum, sumsq) pairs as 16-byte chunks (two blocks each; a last odd
-        // block as a pair) and xor-reduce; fp64 for E[x^2] - mean^2
-        int ln_tm, ln_tn;
-        sk_tile_coords<(BM >= 64)>(p, ln_tile0, ln_tm, ln_tn);
-        const int nch = g.ln_nblk >> 1;
+        if constexpr (APRO == 2) {
+            // the 4 lanes that hold one fragment row (kq = 0..3) split the producer's per-16-column (sum, M2) pairs as 16-byte chunks (two blocks each; a last odd
+            // block as a pair) and xor-reduce; combined in fp64 (RowStatAcc)
+            int ln_tm, ln_tn;
+            sk_tile_coords<(BM >= 64)>(p, ln_tile0, ln_tm, ln_tn);
+            const int nch = g.ln_nblk >> 1;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int gmc = min(ln_tm * BM + (wm * TM + i) * 16 + r16, g.M - 1);
-            const float* st0 = g.ln_stats + (size_t)gmc * g.ln_nblk * 2;
-            const bool vec = (((size_t)gmc * g.ln_nblk) & 1) == 0;  // 16-byte aligned row of pairs (always when ln_nblk is even)
-            double sm = 0.0, q = 0.0;
-            if (vec) {
-                const f32x4* stp = reinterpret_cast<const f32x4*>(st0);
-                int j = kq;
-                for (; j + 12 < nch; j += 16) {  // 4 independent loads in flight
-                    const f32x4 v0 = stp[j], v1 = stp[j + 4], v2 = stp[j + 8], v3 = stp[j + 12];
-                    sm += ((double)v0[0] + (double)v0[2]) + ((double)v1[0] + (double)v1[2]) + ((double)v2[0] + (double)v2[2]) + ((double)v3[0] + (double)v3[2]);
-                    q += ((double)v0[1] + (double)v0[3]) + ((double)v1[1] + (double)v1[3]) + ((double)v2[1] + (double)v2[3]) + ((double)v3[1] + (double)v3[3]);
+            for (int i = 0; i < TM; ++i) {
+                const int gmc = min(ln_tm * BM + (wm * TM + i) * 16 + r16, g.M - 1);
+                const float* st0 = g.ln_stats + (size_t)gmc * g.ln_nblk * 2;
+                const bool vec = (((size_t)gmc * g.ln_nblk) & 1) == 0;  // 16-byte aligned row of pairs (always when ln_nblk is even)
+                RowStatAcc acc;
+                if (vec) {
+                    const f32x4* stp = reinterpret_cast<const f32x4*>(st0);
+                    int j = kq;
+                    for (; j + 12 < nch; j += 16) {  // 4 independent loads in flight
+                        const f32x4 v0 = stp[j], v1 = stp[j + 4], v2 = stp[j + 8], v3 = stp[j + 12];
+                        acc.add(v0[0], v0[1]); acc.add(v0[2], v0[3]); acc.add(v1[0], v1[1]); acc.add(v1[2], v1[3]);
+                        acc.add(v2[0], v2[1]); acc.add(v2[2], v2[3]); acc.add(v3[0], v3[1]); acc.add(v3[2], v3[3]);
+                    }
+                    for (; j < nch; j += 4) {
+                        const f32x4 v0 = stp[j];
+                        acc.add(v0[0], v0[1]); acc.add(v0[2], v0[3]);
+                    }
+                    if ((g.ln_nblk & 1) && kq == 0) acc.add(st0[2 * (g.ln_nblk - 1)], st0[2 * (g.ln_nblk - 1) + 1]);
+                } else {
+                    for (int j = kq; j < g.ln_nblk; j += 4) acc.add(st0[2 * j], st0[2 * j + 1]);
                 }
-                for (; j < nch; j += 4) {
-                    const f32x4 v0 = stp[j];
-                    sm += (double)v0[0] + (double)v0[2];
-                    q += (double)v0[1] + (double)v0[3];
-                }
-                if ((g.ln_nblk & 1) && kq == 0) { sm += (double)st0[2 * (g.ln_nblk - 1)]; q += (double)st0[2 * (g.ln_nblk - 1) + 1]; }
-            } else {
-                for (int j = kq; j < g.ln_nblk; j += 4) { sm += (double)st0[2 * j]; q += (double)st0[2 * j + 1]; }
+                acc.S += __shfl_xor(acc.S, 16, 64); acc.Q += __shfl_xor(acc.Q, 16, 64); acc.M += __shfl_xor(acc.M, 16, 64);
+                acc.S += __shfl_xor(acc.S, 32, 64); acc.Q += __shfl_xor(acc.Q, 32, 64); acc.M += __shfl_xor(acc.M, 32, 64);
+                acc.finish(g.K, g.ln_eps, fr_mu[i], fr_rs[i]);
+                fr_mu_lo[i] = (float)(acc.S / (double)g.K - (double)fr_mu[i]);
+                ln_dir[i] = __builtin_amdgcn_ballot_w64(fabsf(fr_mu[i]) * fr_rs[i] > g.ln_fold_ratio) != 0;  // wave-uniform, a function of the block's 16 rows only
+                ln_any = ln_any || ln_dir[i];
             }
-            sm += __shfl_xor(sm, 16, 64); q += __shfl_xor(q, 16, 64);
-            sm += __shfl_xor(sm, 32, 64); q += __shfl_xor(q, 32, 64);
-            const double mean = sm / (double)g.K;
-            const double var = q / (double)g.K - mean * mean;
-            fr_mu[i] = (float)mean;
-            fr_rs[i] = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + (double)g.ln_eps));
         }
     };
+    // operand-side LayerNorm of an A fragment (row block i, 4 consecutive k from kbase) -- only for blocks flagged by ln_row_stats; zero past K like the staged K tail
+    auto ln_fix = [&](f32x4& a, int i, int kbase) __attribute__((always_inline)) {
+        if constexpr (APRO == 2) {
+            if (ln_dir[i]) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[e] = (kbase + e < g.K) ? ((a[e] - fr_mu[i]) - fr_mu_lo[i]) * fr_rs[i] : 0.f;
+            }
+        }
+    };
+    int kt_cur = 0;  // K step of the unit being multiplied (non-ring loops; the ring / DMA tiles need K % BK == 0 and pass kbase = 0)
 
     auto load_unit = [&](Stage& r, int dma_slot) __attribute__((always_inline)) {  // loads the unit under the load cursor (DMA operands: into LDS stage dma_slot)
         float* dAs = smem + dma_slot * (RING > 0 ? STAGE_FLOATS : TILE_FLOATS) + (wave * (64 / SL)) * BK;  // this wave's first row group of the stage (wave-uniform -> M0)
@@ -308,7 +335,11 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (TM * TN == 1 ? (RING == 3
             for (int i = 0; i < LB; ++i) dma_b128_to_lds(rsrcW, dBs + i * RP * BK, boff[i], kofs);
             if (GRN_SIDE && wave == NW - 1) {  // the side stage: 1 KB of shift (8 copies of the 128-byte row) [, 1 KB of gamma], 1 KB of scale / gx rows
                 float* dX = smem + dma_slot * STAGE_FLOATS + TILE_FLOATS;
-                if (APRO == 4) {  // lanes 0..7 only: one 128-byte row each of shift and gamma (an LDS-DMA writes M0 + lane * 16 for the ACTIVE lanes)
+                if (BIG) {  // shift row by lanes 0..7, then two DMAs of 8 sample rows each
+                    if (lane_k < 8) dma_b128_to_lds(rsrcT, dX, (unsigned)(lane_k * 16), kofs);
+                    dma_b128_to_lds(rsrcS, dX + 64, aux_s_off, kofs);
+                    dma_b128_to_lds(rsrcS, dX + 64 + 256, aux_s_off2, kofs);
+                } else if (APRO == 4) {  // lanes 0..7 only: one 128-byte row each of shift and gamma (an LDS-DMA writes M0 + lane * 16 for the ACTIVE lanes)
                     if (lane_k < 8) {
                         dma_b128_to_lds(rsrcT, dX, (unsigned)(lane_k * 16), kofs);
                         dma_b128_to_lds(rsrcG, dX + 32, (unsigned)(lane_k * 16), kofs);
@@ -374,7 +405,7 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (TM * TN == 1 ? (RING == 3
     // so every ds_read runs under MFMAs that do not need it and the store sits between two MFMA runs; same 48 fragment registers.
     constexpr bool PIPE = (NW == 8 && PD == 1 && TM * TN == 8 && BK == 32 && !TAIL);
     f32x4 Fa[KG][TM], Fb[KG][TN];  // PIPE only: fragments by k group; group 0 belongs to the unit ahead during a unit's last quarter
-    auto read_group = [&](auto kk_tag, int slot) __attribute__((always_inline)) {
+    auto read_group = [&](auto kk_tag, int slot, int kt) __attribute__((always_inline)) {
         constexpr int kk = decltype(kk_tag)::value;
         const float* As = smem + slot * TILE_FLOATS;
         const float* Bs = As + BM * BK;
@@ -383,6 +414,10 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (TM * TN == 1 ? (RING == 3
         for (int i = 0; i < TM; ++i) {
             const int row = (wm * TM + i) * 16 + r16;
             Fa[kk][i] = *reinterpret_cast<const f32x4*>(As + row * BK + ((c4 ^ (row & (SL - 1))) << 2));
+        }
+        if (APRO == 2 && ln_any) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) ln_fix(Fa[kk][i], i, kt * BK + c4 * 4);
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -426,6 +461,12 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (TM * TN == 1 ? (RING == 3
                     bf[kk][j] = *reinterpret_cast<const f32x4*>(Bs + row * BK + ((c4 ^ (row & (SL - 1))) << 2));
                 }
             }
+            if (APRO == 2 && ln_any) {
+#pragma unroll
+                for (int kk = 0; kk < KG; ++kk)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) ln_fix(af[kk][i], i, kt_cur * BK + (kk * 4 + kq) * 4);
+            }
             if (DUAL) {
 #pragma unroll
                 for (int kk = 0; kk < KG; kk += 2)
@@ -459,6 +500,10 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (TM * TN == 1 ? (RING == 3
                 for (int j = 0; j < TN; ++j) {
                     const int row = (wn * TN + j) * 16 + r16;
                     bf[j] = *reinterpret_cast<const f32x4*>(Bs + row * BK + ((c4 ^ (row & (SL - 1))) << 2));
+                }
+                if (APRO == 2 && ln_any) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) ln_fix(af[i], i, kt_cur * BK + c4 * 4);
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
@@ -526,8 +571,8 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (TM * TN == 1 ? (RING == 3
             __syncthreads();  // the scratch is reused by this workgroup's next tile
             return;
         }
-        f32x4 qq[RING > 0 ? TM : 1][RING > 0 ? TN : 1];  // ring tiles: per 16-row block, column sums of squares (GRN finished in the epilogue)
-        const bool grn_fin = RING > 0 && g.ep.grn_gx_out != nullptr;  // kernel-uniform
+        f32x4 qq[GRN_FIN ? TM : 1][GRN_FIN ? TN : 1];  // ring tiles: per 16-row block, column sums of squares (GRN finished in the epilogue)
+        const bool grn_fin = GRN_FIN && g.ep.grn_gx_out != nullptr;  // kernel-uniform
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int m = m0 + (wm * TM + i) * 16 + r16;
@@ -538,11 +583,13 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (TM * TN == 1 ? (RING == 3
                 f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (ok) {
                     f32x4 a = acc[i][j];
-                    if (APRO == 2) a = (a - *reinterpret_cast<const f32x4*>(g.ln_wsum + nn) * fr_mu[i]) * fr_rs[i];  // the folded LayerNorm (see ln_row_stats)
+                    if constexpr (APRO == 2) {
+                        if (!ln_dir[i]) a = (a - *reinterpret_cast<const f32x4*>(g.ln_wsum + nn) * fr_mu[i]) * fr_rs[i];  // the folded LayerNorm (see ln_row_stats)
+                    }
                     v = epilogue_apply(g.ep, g.N, m, nn, a);
                     epilogue_write(g.ep, g.C, g.ldc, m, nn, v);
                 }
-                if constexpr (RING > 0) {
+                if constexpr (GRN_FIN) {
                     if (grn_fin) {
                         f32x4 q = v * v;
 #pragma unroll
@@ -567,11 +614,9 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (TM * TN == 1 ? (RING == 3
                     const int mg = m0 + (wm * TM + i) * 16;
                     if (r16 == 0 && nn < g.N && mg < g.M) *reinterpret_cast<f32x4*>(g.ep.sumsq_out + (size_t)(mg >> 4) * g.N + nn) = q;
                 }
-                if (g.ep.rowstat_out) {  // kernel-uniform: per-row (sum, sum of squares) over this 16-column block (LayerNorm-on-load)
-                    float rs = (v[0] + v[1]) + (v[2] + v[3]);
-                    float rq = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-                    rs += __shfl_xor(rs, 16, 64); rq += __shfl_xor(rq, 16, 64);
-                    rs += __shfl_xor(rs, 32, 64); rq += __shfl_xor(rq, 32, 64);
+                if (g.ep.rowstat_out) {  // kernel-uniform: per-row (sum, centred sum of squares) over this 16-column block (LayerNorm-on-load; gemm_device.h)
+                    float rs, rq;
+                    rowstat_block(v, rs, rq);
                     const int nb = n0 + (wn * TN + j) * 16;
                     if (kq == 0 && m < g.M && nb < g.N) {
                         float* dstp = g.ep.rowstat_out + ((size_t)m * (g.N >> 4) + (nb >> 4)) * 2;
@@ -580,7 +625,7 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (TM * TN == 1 ? (RING == 3
                 }
             }
         }
-        if constexpr (RING > 0) {
+        if constexpr (GRN_FIN) {
             if (grn_fin) {
                 // GlobalResponseNorm's Gx[sample][column] = sqrt(sum over the sample's rows of value^2) finished HERE (reference src/modules.py:37), plus the
                 // sum of Gx over this wave's columns -- the consumer adds grn_np such numbers per sample for mean_k Gx.  The host launches this only
@@ -755,6 +800,12 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (TM * TN == 1 ? (RING == 3
                     bf[kk][j] = *reinterpret_cast<const f32x4*>(Bs + row * BK + ((c4 ^ (row & (SL - 1))) << 2));
                 }
             }
+            if (APRO == 2 && ln_any) {  // (K % 32 == 0 on ring tiles: no K tail to mask)
+#pragma unroll
+                for (int kk = 0; kk < KG; ++kk)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) ln_fix(af[kk][i], i, 0);
+            }
             if (APRO == 1) {  // GlobalResponseNorm apply on the fragments: a' = a * scale[sample][k] + shift[k] (same expression as the staged form)
                 const float* X = Bs + BN * BK;
 #pragma unroll
@@ -814,7 +865,7 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (TM * TN == 1 ? (RING == 3
             }
         };
         constexpr int PER_UNIT = LA + LB;  // LDS-DMA instructions per unit and wave; the last wave issues 2 (APRO 1) / 3 (APRO 4) more with the GRN side stage
-        constexpr int SIDE_DMAS = APRO == 4 ? 3 : 2;
+        constexpr int SIDE_DMAS = (APRO == 4 || BIG) ? 3 : 2;
 #pragma unroll
         for (int j = 0; j < RING - 1; ++j) fetch_ring(j);
         ln_row_stats();  // while the first units are in flight
@@ -822,6 +873,107 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (TM * TN == 1 ? (RING == 3
         int ctile = (int)(u0 / (unsigned)KT);
         int ckt = (int)(u0 - (unsigned)ctile * (unsigned)KT);
         bool first_seg = true;
+        if constexpr (BIG) {
+            // ===== 8 waves x (64x64 wave tile): fragments by 16-wide k group, read one group ahead of the MFMAs =====
+            //   barrier(u) | DMA unit u+2 -> the stage unit u-1 left | read group 0 of unit u | MFMA group 1 of unit u-1 | read group 1 of unit u | MFMA group 0 of unit u
+            // Every ds_read runs under 64 MFMAs that do not need it (the GRN scale / shift fragments ride with the operand fragments and are applied right
+            // before the group multiplies); the matrix core only waits at the first unit of a tile.
+            f32x4 Sg[APRO == 1 ? KG : 1][APRO == 1 ? TM : 1], Tg[APRO == 1 ? KG : 1];
+            auto big_read = [&](auto kk_tag, int st) __attribute__((always_inline)) {
+                constexpr int kk = decltype(kk_tag)::value;
+                const float* As = smem + st * STAGE_FLOATS;
+                const float* Bs = As + BM * BK;
+                const int c4 = kk * 4 + kq;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int row = (wm * TM + i) * 16 + r16;
+                    Fa[kk][i] = *reinterpret_cast<const f32x4*>(As + row * BK + ((c4 ^ (row & (SL - 1))) << 2));
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int row = (wn * TN + j) * 16 + r16;
+                    Fb[kk][j] = *reinterpret_cast<const f32x4*>(Bs + row * BK + ((c4 ^ (row & (SL - 1))) << 2));
+                }
+                if constexpr (APRO == 1) {
+                    const float* X = Bs + BN * BK;
+                    Tg[kk] = *reinterpret_cast<const f32x4*>(X + c4 * 4);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) Sg[kk][i] = *reinterpret_cast<const f32x4*>(X + 64 + sidx[i] * 32 + c4 * 4);
+                }
+            };
+            auto big_xform = [&](auto kk_tag) __attribute__((always_inline)) {  // GlobalResponseNorm apply on the fragments: a' = a * scale[sample][k] + shift[k]
+                constexpr int kk = decltype(kk_tag)::value;
+                if constexpr (APRO == 1) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) Fa[kk][i] = Fa[kk][i] * Sg[kk][i] + Tg[kk];
+                }
+                if (APRO == 2 && ln_any) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) ln_fix(Fa[kk][i], i, 0);
+                }
+            };
+            using I0 = std::integral_constant<int, 0>;
+            using I1 = std::integral_constant<int, 1>;
+            using I4 = std::integral_constant<int, 4>;
+            static_assert(KG == 2, "two k groups per K step");
+            // which of the two waves of a SIMD runs the late order: waves w and w + 4 share a SIMD (round-robin placement); p.stagger 2 = by wave parity, 0 = off (A/B)
+            const bool late = p.stagger == 1 ? wave >= NW / 2 : (p.stagger == 2 ? (wave & 1) != 0 : false);
+            for (int i = 0; i < n;) {
+                const int seg_len = min(KT - ckt, n - i);
+                enter_tile(ctile);
+                bool pend = false;  // group 1 of the previous unit is still to be multiplied
+                for (int s2 = 0; s2 < seg_len; ++s2) {
+                    // this wave's share of unit u has landed and its reads of the stage that is about to be overwritten (issued two MFMA groups ago) are done
+                    if (GRN_SIDE && wave == NW - 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((RING - 2) * (PER_UNIT + SIDE_DMAS)) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((RING - 2) * PER_UNIT) : "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    // The two waves that share a SIMD come out of the barrier together.  If both then issue their 6 LDS-DMA pieces (60-185 cycles of issue each,
+                    // MI355X_MICROARCH.md) and 8 fragment reads, the matrix core idles for ~10 % of the unit.  STAGGER: one of them multiplies the pending k group
+                    // first and does its non-MFMA work while the other one is in its MFMA block, and vice versa.
+                    if (!late) {
+                        fetch_ring(ls);
+                        __builtin_amdgcn_sched_barrier(0);
+                        big_read(I0{}, cs);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (pend) {
+                            big_xform(I1{});
+                            mfma_group(I1{}, I0{}, I4{});
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        big_read(I1{}, cs);
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else {
+                        if (pend) {
+                            big_xform(I1{});
+                            mfma_group(I1{}, I0{}, I4{});
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        fetch_ring(ls);
+                        __builtin_amdgcn_sched_barrier(0);
+                        big_read(I0{}, cs);
+                        big_read(I1{}, cs);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    big_xform(I0{});
+                    mfma_group(I0{}, I0{}, I4{});
+                    __builtin_amdgcn_sched_barrier(0);
+                    pend = true;
+                    cs = cs + 1 == RING ? 0 : cs + 1;
+                    ls = ls + 1 == RING ? 0 : ls + 1;
+                }
+                big_xform(I1{});
+                mfma_group(I1{}, I0{}, I4{});
+                __builtin_amdgcn_sched_barrier(0);
+                if (i + seg_len == n) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may still be landing when the workgroup's LDS is released
+                flush(ctile, ckt, ckt + seg_len, first_seg);
+                first_seg = false;
+                i += seg_len;
+                ckt += seg_len;
+                if (ckt == KT) { ckt = 0; ++ctile; }
+            }
+            return;
+        }
         for (int i = 0; i < n;) {
             const int seg_len = min(KT - ckt, n - i);
             enter_tile(ctile);
@@ -868,7 +1020,7 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (TM * TN == 1 ? (RING == 3
     ln_row_stats();  // while the first units are in flight
     store_unit(R[0], 0);
     __syncthreads();
-    if constexpr (PIPE) read_group(std::integral_constant<int, 0>{}, 0);
+    if constexpr (PIPE) read_group(std::integral_constant<int, 0>{}, 0, (int)(u0 % (unsigned)KT));
 
     int ctile = (int)(u0 / (unsigned)KT);
     int ckt = (int)(u0 - (unsigned)ctile * (unsigned)KT);
@@ -885,14 +1037,14 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (TM * TN == 1 ? (RING == 3
         fetch(rf, sl ^ 1);  // DMA operands of the next unit start landing in the other LDS stage now (last read before the previous barrier)
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (PIPE) {
-            read_group(I1{}, sl);  // k group 1 of this unit; group 0 was read behind the previous barrier
+            read_group(I1{}, sl, kt_cur);  // k group 1 of this unit; group 0 was read behind the previous barrier
             __builtin_amdgcn_sched_barrier(0);
             mfma_group(I0{}, I0{}, I4{});
             mfma_group(I1{}, I0{}, I2{});
             __builtin_amdgcn_sched_barrier(0);
             store_unit(rs, sl ^ 1);
             __syncthreads();
-            read_group(I0{}, sl ^ 1);  // k group 0 of the next unit
+            read_group(I0{}, sl ^ 1, kt_cur + 1);  // k group 0 of the next unit (a LayerNorm-consuming launch never leaves its tile: the next K step)
             __builtin_amdgcn_sched_barrier(0);
             mfma_group(I1{}, I2{}, I4{});
             __builtin_amdgcn_sched_barrier(0);
@@ -902,6 +1054,7 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (TM * TN == 1 ? (RING == 3
             store_unit(rs, sl ^ 1);
             __syncthreads();
         }
+        ++kt_cur;
     };
     // A segment's units with COMPILE-TIME LDS stages and ring roles (immediate LDS offsets, statically indexed register stages):
     // two instantiations, by the LDS stage the segment starts in.  A segment of odd length leaves the ring in phase 1, so it is
@@ -928,6 +1081,7 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (TM * TN == 1 ? (RING == 3
     };
     for (int i = 0; i < n;) {
         const int seg_len = min(KT - ckt, n - i);
+        kt_cur = ckt;
         if (slot == 0) run_segment(std::integral_constant<int, 0>{}, seg_len);
         else run_segment(std::integral_constant<int, 1>{}, seg_len);
         slot ^= seg_len & 1;
@@ -988,6 +1142,8 @@ static const TileCfg kCfgs[] = {
     {2, 2, 2, 1, 1, 32, 3},  // 33: 64x32, 3 stages
     {2, 2, 2, 2, 1, 32, 3},  // 34: 64x64, 3 stages
     {2, 2, 1, 2, 1, 32, 4},  // 35: 32x64, 4 stages
+    // the throughput-regime tile: 8 waves of 64x64 wave tiles, both operands by LDS-DMA into 3 stages, fragments read one k group ahead (BIG in the kernel)
+    {4, 2, 4, 4, 1, 32, 3},  // 36: 256x128
 };
 static const int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 int gemm_num_tile_configs() { return kNumCfgs; }
@@ -1002,7 +1158,8 @@ static bool conv_cfg(int cfg) { return cfg == 2 || cfg == 5 || cfg == 9 || cfg =
 // tile configs that carry the direct-to-LDS (DMA) twin: the two large-problem workhorses (ids 10 and 18) and the 1-deep 32x32 tile (id 19)
 template <int WM, int WN, int TM, int TN, int PD, int BK>
 static constexpr bool dma_tile() {
-    return BK == 32 && PD == 1 && ((WM == 2 && WN == 4 && TM == 4 && TN == 2) || (WM == 2 && WN == 2 && TM == 2 && TN == 2) || (WM == 2 && WN == 2 && TM == 1 && TN == 1));
+    return BK == 32 && PD == 1 && ((WM == 2 && WN == 4 && TM == 4 && TN == 2) || (WM == 2 && WN == 2 && TM == 2 && TN == 2) || (WM == 2 && WN == 2 && TM == 1 && TN == 1) ||
+                                   (WM == 2 && WN == 2 && TM == 4 && TN == 4));  // (id 0: 128x128 on 4 waves of 64x64 wave tiles, two workgroups per CU)
 }
 static std::atomic<int> g_gemm_raster_gm{8};  // tile rows per rasterisation group (0 = plain m-fastest); test hook
 extern "C" int paella_test_gemm_raster(int gm) { g_gemm_raster_gm = gm; return PAELLA_OK; }
@@ -1021,11 +1178,26 @@ static void launch_ring(const GemmArgs& g, const SkPlan& p, unsigned G, float* s
         hipLaunchKernelGGL((gemm_nt_kernel<2, 2, TM, TN, 1, 0, false, 32, false, RING>), dim3(G), dim3(256), 0, st, g, p, slabs, tickets, slab_bytes);
 }
 
+static void launch_big(const GemmArgs& g, const SkPlan& p, unsigned G, float* slabs, unsigned* tickets, unsigned slab_bytes, hipStream_t st) {
+    if (g.a_scale)
+        hipLaunchKernelGGL((gemm_nt_kernel<4, 2, 4, 4, 1, 1, false, 32, false, 3>), dim3(G), dim3(512), 0, st, g, p, slabs, tickets, slab_bytes);
+    else if (g.ln_stats)
+        hipLaunchKernelGGL((gemm_nt_kernel<4, 2, 4, 4, 1, 2, false, 32, false, 3>), dim3(G), dim3(512), 0, st, g, p, slabs, tickets, slab_bytes);
+    else
+        hipLaunchKernelGGL((gemm_nt_kernel<4, 2, 4, 4, 1, 0, false, 32, false, 3>), dim3(G), dim3(512), 0, st, g, p, slabs, tickets, slab_bytes);
+}
+
 template <int WM, int WN, int TM, int TN, int PD, int BK>
 static void launch_one(const GemmArgs& g, const SkPlan& p, unsigned G, float* slabs, unsigned* tickets, unsigned slab_bytes, hipStream_t st) {
     constexpr int NT = 64 * WM * WN;
     if constexpr (dma_tile<WM, WN, TM, TN, PD, BK>()) {
-        if (g_gemm_dma && g.K % BK == 0) {  // no K tail: operands without a transform go global -> LDS directly
+        constexpr bool plain_only = (WM * WN == 4 && TM * TN == 16);  // (the 4-wave 128x128 twin spills with a prologue's extra operands: plain GEMMs only)
+        if constexpr (plain_only) {
+            if (g_gemm_dma && g.K % BK == 0 && !g.cv.enabled && !g.a_scale && !g.ln_stats) {
+                hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, PD, 0, false, BK, true>), dim3(G), dim3(NT), 0, st, g, p, slabs, tickets, slab_bytes);
+                return;
+            }
+        } else if (g_gemm_dma && g.K % BK == 0) {  // no K tail: operands without a transform go global -> LDS directly
             if (g.cv.enabled)
                 hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, PD, 3, false, BK, true>), dim3(G), dim3(NT), 0, st, g, p, slabs, tickets, slab_bytes);
             else if (g.a_scale)
@@ -1054,7 +1226,8 @@ static void launch_one(const GemmArgs& g, const SkPlan& p, unsigned G, float* sl
 // ring tiles: both operands by LDS-DMA (whole K steps only), GRN side stage holds the scale rows of at most 8 consecutive samples
 static bool ring_ok(const GemmArgs& g, int BM) {
     if (g.K % 32 || g.cv.enabled) return false;
-    if ((g.a_scale || g.grn_gx) && (BM - 1) / (g.a_rows_per_sample > 0 ? g.a_rows_per_sample : 1) + 2 > 8) return false;
+    const int side_samples = BM >= 256 ? 16 : 8;  // sample rows the GRN side stage holds (the 8-wave 256-row tile: 16)
+    if ((g.a_scale || g.grn_gx) && (BM - 1) / (g.a_rows_per_sample > 0 ? g.a_rows_per_sample : 1) + 2 > side_samples) return false;
     return true;
 }
 static inline long tiles_of_cfg(int c, int M, int N) {
@@ -1076,13 +1249,29 @@ static inline long tiles_of_cfg(int c, int M, int N) {
 //    (__launch_bounds__(256, 5) on that instantiation guarantees the registers for it) -- every larger
 //    tile lands within 5 % of it (24-27 us for 128x5120x1280): these launches are bound by ramp + combine, not by the tile.
 // ring tile used for the skinny batch-1 shapes (30..35; 0 = the register-staged / 1-deep DMA kernels of round 2, kept for A/B).  Default 30 (32x32,
-// 3 stages; the LayerNorm-prologue GEMMs take its 4-stage sibling 31).  Test hook + PAELLA_GEMM_RING env override.
-static std::atomic<int> g_gemm_ring{[]() { const char* e = getenv("PAELLA_GEMM_RING"); return e ? atoi(e) : 30; }()};
+// 3 stages; the LayerNorm-prologue GEMMs take its 4-stage sibling 31).  A/B only through the test hook (test_hooks.h); no environment switches.
+static std::atomic<int> g_gemm_ring{30};
 extern "C" int paella_test_gemm_ring(int cfg) {
-    if (cfg != 0 && (cfg < 30 || cfg >= kNumCfgs)) { paella_set_error("ring tile config must be 0 or 30..%d", kNumCfgs - 1); return PAELLA_ERR_ARG; }
+    if (cfg != 0 && (cfg < 30 || cfg > 35)) { paella_set_error("ring tile config must be 0 or 30..35"); return PAELLA_ERR_ARG; }
     g_gemm_ring = cfg;
     return PAELLA_OK;
 }
+// throughput-regime tile (id 36, 256x128 on 8 waves): 0 = never (the round-3 rules: 64x64 / 128x128 tiles), 1 = launches with >= kBigMinTiles tiles of 256x128
+// (one tile per workgroup), 2 = those + the batched mid-size shapes as ONE persistent workgroup per CU on balanced unit ranges.  Test hook for A/B.
+static std::atomic<int> g_gemm_big{2};
+extern "C" int paella_test_gemm_big(int mode) {
+    if (mode < 0 || mode > 2) { paella_set_error("big-tile mode must be 0, 1 or 2"); return PAELLA_ERR_ARG; }
+    g_gemm_big = mode;
+    return PAELLA_OK;
+}
+static std::atomic<int> g_gemm_big_stagger{1};  // SkPlan::stagger of the 256x128 tile (A/B through the test hook)
+extern "C" int paella_test_gemm_big_stagger(int mode) {
+    if (mode < 0 || mode > 2) { paella_set_error("stagger mode must be 0, 1 or 2"); return PAELLA_ERR_ARG; }
+    g_gemm_big_stagger = mode;
+    return PAELLA_OK;
+}
+static std::atomic<int> g_grn_fuse{1};  // 0 = always the grn_from_partials finalize launch between the two MLP GEMMs (A/B)
+extern "C" int paella_test_grn_fuse(int on) { g_grn_fuse = on != 0; return PAELLA_OK; }
 // The MLP pair gelu(h W1^T) -> GRN -> W2 of one ResBlock / FeedForwardBlock can skip the GRN finalize launch when (a) both GEMMs are in the skinny class
 // the ring tiles serve, (b) the producer's tile rows cover whole samples: 16 rows per sample -> any ring tile (32x32 here), 64 -> the 64x32 tile.
 // Returns the ring tile GEMM1 must use (its grn_np is then (N1 / 32) * 2), or 0.
@@ -1090,8 +1279,7 @@ extern "C" int paella_test_gemm_ring(int cfg) {
 // per sample the 64x32 producer tile (4 parts per tile to combine instead of 2, cross-wave reduction in the epilogue) costs +7.6 us -- more than the
 // launch it removes -- so the model asks with allow_64 = false and keeps the finalize launch there.
 int gemm_grn_fused_tile(int M, int C4, int C, int rows_per_sample, bool allow_64) {
-    static const int enabled = []() { const char* e = getenv("PAELLA_GRN_FUSE"); return e ? atoi(e) : 1; }();  // A/B switch
-    if (!enabled || !g_gemm_ring.load(std::memory_order_relaxed) || gemm_precision() != 0) return 0;
+    if (!g_grn_fuse.load(std::memory_order_relaxed) || !g_gemm_ring.load(std::memory_order_relaxed) || gemm_precision() != 0) return 0;
     if ((C & 31) || (C4 & 31) || M % rows_per_sample) return 0;
     const double macs = (double)M * C4 * C;
     const long T64 = (long)((M + 63) / 64) * ((C4 + 63) / 64);
@@ -1111,7 +1299,7 @@ static long ring_resident(int cfg, int apro) {
     }
 }
 
-static void choose_config(int M, int N, int K, int apro, bool ring_allowed, int force_ring, size_t slab_cap_bytes, int* cfg_out, unsigned* G_out) {
+static void choose_config(int M, int N, int K, int apro, bool ring_allowed, bool big_allowed, int force_ring, size_t slab_cap_bytes, int* cfg_out, unsigned* G_out) {
     // one consistent value per decision; force_ring: the caller needs THIS ring tile in the skinny class (its epilogue finishes GRN per tile)
     const int g_gemm_ring = ::g_gemm_ring.load(std::memory_order_relaxed) ? (force_ring > 0 ? force_ring : ::g_gemm_ring.load(std::memory_order_relaxed)) : 0;
     const long ktiles = (K + 31) / 32;
@@ -1119,7 +1307,19 @@ static void choose_config(int M, int N, int K, int apro, bool ring_allowed, int 
     const long T128 = tiles_of_cfg(10, M, N), T64 = tiles_of_cfg(18, M, N), T32 = tiles_of_cfg(5, M, N);
     int cfg;
     long G;
-    if (T128 >= 1024) {
+    const int big_mode = big_allowed ? g_gemm_big.load(std::memory_order_relaxed) : 0;
+    const long T256 = tiles_of_cfg(36, M, N);
+    // one 256x128 tile per workgroup leaves CUs idle in its last round: fraction of the rounds' slots that do work
+    const double big_fill = (double)T256 / (256.0 * (double)((T256 + 255) / 256));
+    if (big_mode >= 1 && (T256 >= 1024 || (T256 >= 224 && big_fill >= 0.85 && macs >= 2.5e9))) {
+        // the throughput regime (batch 32 and up, BASELINE configs[2]): 256x128 tiles on 8 waves, one tile per workgroup = one workgroup per CU; tiles that
+        // run together on an XCD share panels in its L2 (grouped rasterisation), the prefetch ring and the k-group-ahead fragment reads keep the matrix
+        // cores fed (profiles/r04_gemm_big_sweep.txt)
+        cfg = 36; G = T256;
+    } else if (big_mode >= 2 && macs >= 2.5e9 && apro != 2 && T256 >= 64) {
+        // batched mid-size shapes: the same tile as ONE persistent workgroup per CU on balanced (tile, K-step) ranges
+        cfg = 36; G = 256;
+    } else if (T128 >= 1024) {
         // plain operands: 64x64 tiles, 4 independent workgroups per CU, grouped rasterisation (140 TFLOP/s on 32768x5120x1280);
         // with a prologue the 8-wave 128x128 tile stages the A operand half as often and ties or wins
         // (a LayerNorm-consuming GEMM multiplies the raw operand since round 3 -- the normalisation is folded into its epilogue -- and takes the plain rule:
@@ -1219,7 +1419,13 @@ static int prof_bracket(const GemmArgs& g, hipStream_t st, bool stores_c, F&& la
     return rc;
 }
 
-int launch_gemm_cfg(const GemmArgs& g, int cfg, int splitk, void* ws, size_t ws_bytes, hipStream_t st) {
+// threshold of the LayerNorm fold (gemm_device.h: kLnFoldMaxRatio); the test hook moves it to measure the fold's error curve (inf = always fold, 0 = never)
+static std::atomic<float> g_ln_fold_ratio{kLnFoldMaxRatio};
+extern "C" int paella_test_ln_fold_ratio(float ratio) { g_ln_fold_ratio = ratio; return PAELLA_OK; }
+
+int launch_gemm_cfg(const GemmArgs& g_in, int cfg, int splitk, void* ws, size_t ws_bytes, hipStream_t st) {
+    GemmArgs g = g_in;
+    g.ln_fold_ratio = g_ln_fold_ratio.load(std::memory_order_relaxed);
     return prof_bracket(g, st, true, [&]() { return launch_gemm_cfg_impl(g, cfg, splitk, ws, ws_bytes, st); });
 }
 
@@ -1304,7 +1510,7 @@ static int launch_gemm_cfg_impl(const GemmArgs& g, int cfg, int splitk, void* ws
     const size_t slab_cap = have_ws ? ws_bytes - kGemmTicketBytes : 0;
     unsigned G = 0;
     if (cfg < 0) {
-        choose_config(g.M, g.N, g.K, (g.a_scale || g.grn_gx) ? 1 : (g.ln_stats ? 2 : 0), ring_ok(g, 64), g.force_ring_cfg, slab_cap, &cfg, &G);
+        choose_config(g.M, g.N, g.K, (g.a_scale || g.grn_gx) ? 1 : (g.ln_stats ? 2 : 0), ring_ok(g, 64), ring_ok(g, 256) && !g.grn_gx && !g.ep.grn_gx_out, g.force_ring_cfg, slab_cap, &cfg, &G);
         if (g.cv.enabled && !conv_cfg(cfg)) { paella_set_error("internal: heuristic picked tile %d without a convolution variant", cfg); return PAELLA_ERR_STATE; }
     } else {
         if (cfg >= kNumCfgs) { paella_set_error("gemm: bad tile config %d", cfg); return PAELLA_ERR_ARG; }
@@ -1314,7 +1520,7 @@ static int launch_gemm_cfg_impl(const GemmArgs& g, int cfg, int splitk, void* ws
     }
     const TileCfg& tc = kCfgs[cfg];
     const int BM = tc.wm * tc.tm * 16, BN = tc.wn * tc.tn * 16;
-    if ((g.grn_gx || g.ep.grn_gx_out) && !tc.ring) { paella_set_error("gemm: the in-epilogue / on-load GRN statistics need a ring tile (got tile %d)", cfg); return PAELLA_ERR_STATE; }
+    if ((g.grn_gx || g.ep.grn_gx_out) && (!tc.ring || tc.wm * tc.wn == 8)) { paella_set_error("gemm: the in-epilogue / on-load GRN statistics need a ring tile (got tile %d)", cfg); return PAELLA_ERR_STATE; }
     if (g.grn_gx && (!g.grn_gamma || !g.a_shift || !g.grn_part || g.grn_np <= 0 || g.a_scale || g.ln_stats || g.a_rows_per_sample % 16)) {
         paella_set_error("gemm: bad GRN-from-statistics operand description"); return PAELLA_ERR_ARG;
     }
@@ -1355,6 +1561,7 @@ static int launch_gemm_cfg_impl(const GemmArgs& g, int cfg, int splitk, void* ws
     // grouped rasterisation for launches with many tile rows and columns (test hook: paella_test_gemm_raster)
     // (32-row tiles and skinny problems keep the plain order: their traffic is the weight panel, which m-fastest tiles share best --
     // measured +2 % per image at batch 1 with groups there)
+    p.stagger = g_gemm_big_stagger.load(std::memory_order_relaxed);
     const int raster_gm = g_gemm_raster_gm;
     p.gm = (raster_gm > 0 && BM >= 64 && p.tiles_m >= 4 * raster_gm && p.tiles_n >= 4) ? raster_gm : p.tiles_m;
     unsigned* tickets = have_ws ? reinterpret_cast<unsigned*>(ws) : nullptr;
@@ -1400,6 +1607,7 @@ static int launch_gemm_cfg_impl(const GemmArgs& g, int cfg, int splitk, void* ws
         case 33: launch_ring<2, 1, 3>(g, p, G, slabs, tickets, slab_bytes, st); break;
         case 34: launch_ring<2, 2, 3>(g, p, G, slabs, tickets, slab_bytes, st); break;
         case 35: launch_ring<1, 2, 4>(g, p, G, slabs, tickets, slab_bytes, st); break;
+        case 36: launch_big(g, p, G, slabs, tickets, slab_bytes, st); break;
         default: paella_set_error("gemm: bad tile config %d", cfg); return PAELLA_ERR_ARG;
     }
 #undef GEMM_CASE
@@ -1412,8 +1620,8 @@ static int launch_gemm_cfg_impl(const GemmArgs& g, int cfg, int splitk, void* ws
 // head GEMM with the fused sampling tail: one whole tile per workgroup (G = tiles), TAIL instantiations only
 // ---------------------------------------------------------------------------
 // tile of the fused head + tail: 9 = 128x128 (one workgroup per CU: the Philox / log epilogue serialises behind the main loop), 14 = 128x64 8 waves
-// (two or more workgroups per CU overlap epilogue and main loop; twice the per-row partials).  Test hook + PAELLA_GEMM_TAIL_TILE env override for A/B.
-static std::atomic<int> g_tail_tile{[]() { const char* e = getenv("PAELLA_GEMM_TAIL_TILE"); return e ? atoi(e) : 14; }()};
+// (two or more workgroups per CU overlap epilogue and main loop; twice the per-row partials).  A/B through the test hook only.
+static std::atomic<int> g_tail_tile{14};
 extern "C" int paella_test_gemm_tail_tile(int cfg) {
     if (cfg != 9 && cfg != 14) { paella_set_error("fused-tail tile must be 9 (128x128) or 14 (128x64)"); return PAELLA_ERR_ARG; }
     g_tail_tile = cfg;
@@ -1450,6 +1658,7 @@ static int launch_gemm_tail_impl(const GemmArgs& g, hipStream_t st) {
     const unsigned long long G = T;
     p.q = (unsigned)(p.U / G);
     p.r = 0;
+    p.stagger = 0;
     p.gm = p.tiles_m;
     if (cfg == 9) hipLaunchKernelGGL((gemm_nt_kernel<4, 2, 2, 4, 1, 0, true>), dim3((unsigned)G), dim3(512), 0, st, g, p, (float*)nullptr, (unsigned*)nullptr, 0u);
     else if (cfg == 14) hipLaunchKernelGGL((gemm_nt_kernel<4, 2, 2, 2, 2, 0, true>), dim3((unsigned)G), dim3(512), 0, st, g, p, (float*)nullptr, (unsigned*)nullptr, 0u);

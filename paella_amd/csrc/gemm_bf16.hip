@@ -66,14 +66,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g, const unsign
         if (APRO == 1) sptr[i] = g.a_scale + (size_t)(gmc / g.a_rows_per_sample) * g.K;
         if (APRO == 2) {
             const float* stp = g.ln_stats + (size_t)gmc * g.ln_nblk * 2;
-            double s = 0.0, q = 0.0;
-            for (int j = ldc; j < g.ln_nblk; j += 8) { s += (double)stp[2 * j]; q += (double)stp[2 * j + 1]; }
+            RowStatAcc acc;  // (sum, centred M2) partials per 16-column block: gemm_device.h
+            for (int j = ldc; j < g.ln_nblk; j += 8) acc.add(stp[2 * j], stp[2 * j + 1]);
 #pragma unroll
-            for (int o = 1; o < 8; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
-            const double mean = s / (double)g.K;
-            const double var = q / (double)g.K - mean * mean;
-            ln_mu[i] = (float)mean;
-            ln_rs[i] = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + (double)g.ln_eps));
+            for (int o = 1; o < 8; o <<= 1) { acc.S += __shfl_xor(acc.S, o, 64); acc.Q += __shfl_xor(acc.Q, o, 64); acc.M += __shfl_xor(acc.M, o, 64); }
+            acc.finish(g.K, g.ln_eps, ln_mu[i], ln_rs[i]);
         }
     }
 #pragma unroll
@@ -221,10 +218,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g, const unsign
                 if (r16 == 0 && n < g.N && mg < g.M) *reinterpret_cast<f32x4*>(g.ep.sumsq_out + (size_t)(mg >> 4) * g.N + n) = q;
             }
             if (g.ep.rowstat_out) {
-                float rs = (v[0] + v[1]) + (v[2] + v[3]);
-                float rq = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-                rs += __shfl_xor(rs, 16, 64); rq += __shfl_xor(rq, 16, 64);
-                rs += __shfl_xor(rs, 32, 64); rq += __shfl_xor(rq, 32, 64);
+                float rs, rq;
+                rowstat_block(v, rs, rq);
                 const int nb = n0 + (wn * TN + j) * 16;
                 if (kq == 0 && m < g.M && nb < g.N) {
                     float* dstp = g.ep.rowstat_out + ((size_t)m * (g.N >> 4) + (nb >> 4)) * 2;

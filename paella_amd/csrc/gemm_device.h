@@ -53,6 +53,41 @@ __device__ __forceinline__ void epilogue_write(const Epilogue& ep, float* __rest
     }
 }
 
+// ---------------------------------------------------------------------------
+// LayerNorm-on-load row statistics (producer: Epilogue::rowstat_out, consumer: GemmArgs::ln_stats), [M, N/16, 2].
+// Per row and 16-column block the producer leaves (sum, M2) with M2 = sum (v - block mean)^2 -- CENTRED partials, not (sum, sum of squares):
+// the consumer combines them with the parallel-variance formula  M2_total = sum_j M2_j + sum_j s_j^2 / 16 - S^2 / K  in fp64, whose cancellation
+// acts on the EXACTLY representable block sums only.  Relative error of the variance ~ eps * |mean| / std (linear), where the one-pass
+// E[x^2] - mean^2 over fp32 partial sums of squares loses eps * (mean / std)^2 (round 3).
+// ---------------------------------------------------------------------------
+// v = this lane's 4 of the block's 16 values; the block's other 12 live in lanes +-16, +-32 (the kq = 0..3 lanes of a fragment row)
+__device__ __forceinline__ void rowstat_block(const f32x4 v, float& s, float& m2) {
+    s = (v[0] + v[1]) + (v[2] + v[3]);
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    const float mb = s * 0.0625f;
+    const float d0 = v[0] - mb, d1 = v[1] - mb, d2 = v[2] - mb, d3 = v[3] - mb;
+    m2 = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    m2 += __shfl_xor(m2, 16, 64);
+    m2 += __shfl_xor(m2, 32, 64);
+}
+struct RowStatAcc {
+    double S = 0.0, Q = 0.0, M = 0.0;  // sum of block sums, sum of block sums squared, sum of block M2
+    __device__ __forceinline__ void add(float s, float m2) { S += (double)s; Q += (double)s * (double)s; M += (double)m2; }
+    __device__ __forceinline__ void finish(int K, float eps, float& mu, float& rstd) const {
+        const double mean = S / (double)K;
+        const double var = (M + Q * 0.0625 - S * mean) / (double)K;
+        mu = (float)mean;
+        rstd = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + (double)eps));
+    }
+};
+// LayerNorm folded into the consuming GEMM's epilogue, rstd * (acc - mu * wsum[n]), cancels when |mu| >> std: its error is ~ eps * sqrt(K) * |mu| / std
+// relative to the normalised product (measured on K = 1280: 6e-6 * ratio, i.e. 7e-5 at 10, 6e-4 at 100, 5.6e-3 at 1000 against a flat 5e-6 for the
+// operand-side form: profiles/r04_ln_fold_error_curve.txt).  Above this ratio a 16-row fragment block switches to normalising
+// its operand fragments instead ((a - mu) * rstd before the MFMAs; error independent of the ratio).  A wave-uniform decision per 16-row block that
+// depends only on the rows' statistics, so every workgroup that shares a tile takes the same path.
+static constexpr float kLnFoldMaxRatio = 4.0f;  // default of GemmArgs::ln_fold_ratio
+
 __device__ __forceinline__ void epilogue_store(const Epilogue& ep, float* __restrict__ C, int ldc, int N,
                                                int m, int n, f32x4 v) {
     epilogue_write(ep, C, ldc, m, n, epilogue_apply(ep, N, m, n, v));

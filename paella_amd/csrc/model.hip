@@ -61,7 +61,7 @@ struct Block {
     bool ts_standalone = true; // BT_TS: false when fused into the previous block's GEMM epilogue
     int fused_ts = -1;         // BT_RES/BT_FF: ts offset fused into GEMM2, or -1
     int attn_index = -1;
-    bool emit_rowstat = false;   // producer: this block's last GEMM also writes per-row (sum, sumsq) partials of x
+    bool emit_rowstat = false;   // producer: this block's last GEMM also writes per-row (sum, centred M2) partials of x
     bool ln_from_stats = false;  // consumer (ATTN / UP): LayerNorm folded into the GEMM's A-operand load from those partials
     int c_from = 0, c_to = 0;  // samplers
 };

@@ -4,6 +4,7 @@
 #ifndef PAELLA_TEST_HOOKS_H
 #define PAELLA_TEST_HOOKS_H
 #include <stddef.h>
+#include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -14,8 +15,8 @@ int paella_test_launch_chain(float* buf, int n_elems, int blocks, int n_launches
 /* 1 = run large-query-count attention on the register-fed kernel instead of the LDS-staged one (A/B probe, tools/attn_probe.py) */
 int paella_test_attention_variant(int v);
 /* C = prologue(A) . W^T with an explicit tile config / workgroup count (as paella_op_gemm): mode 1: a' = a * scale[row / rows_per_sample][k] +
- * shift[k] (the GRN apply of the MLP's second GEMM); mode 2: a' = (a - mean) * rstd from ln_stats [M, K/16, 2] = per 16-column block (sum, sum of
- * squares) (LayerNorm folded into the consumer's EPILOGUE; the hook sums W's rows itself with one extra M = 1 launch per call) */
+ * shift[k] (the GRN apply of the MLP's second GEMM); mode 2: a' = (a - mean) * rstd from ln_stats [M, K/16, 2] = per 16-column block (sum, M2 =
+ * sum of squared deviations from the block mean) (LayerNorm folded into the consumer's EPILOGUE; the hook sums W's rows itself with one extra M = 1 launch per call) */
 int paella_test_gemm_prologue(const float* A, const float* W, float* C, int M, int N, int K, int mode, const float* scale, const float* shift,
                               int rows_per_sample, const float* ln_stats, int tile_cfg, int splitk, void* ws, size_t ws_bytes, void* stream);
 /* out[M, c] = GRN(gelu(h W1^T + b1)) W2^T with GlobalResponseNorm finished inside the two GEMMs (the batch-1 path of a ResBlock's MLP: no finalize
@@ -30,18 +31,28 @@ int paella_test_gemm_ring(int cfg);
 int paella_test_gemm_tail_tile(int cfg);
 /* tile rows per rasterisation group of the GEMM (default 8); 0 = plain m-fastest tile order (A/B) */
 int paella_test_gemm_raster(int gm);
+/* throughput-regime tile (id 36, 256x128 on 8 waves): 0 = never (round-3 rules), 1 = only launches with many tiles, 2 = also the batched mid-size shapes (default) */
+int paella_test_gemm_big(int mode);
+/* 256x128 tile: which of the two waves that share a SIMD runs its LDS-DMA issue / fragment reads late (under the other one's MFMA block): 0 = neither
+ * (both straight after the barrier), 1 = waves 4..7 (default), 2 = odd waves */
+int paella_test_gemm_big_stagger(int mode);
+/* |mean| / std above which a 16-row block of a LayerNorm-consuming GEMM normalises its operand fragments instead of folding the LayerNorm into the
+ * epilogue (default 4; inf = always fold, 0 = never): measures the fold's error curve (tests/test_gpu_ops.py, profiles/r04_ln_fold_error_curve.txt) */
+int paella_test_ln_fold_ratio(float ratio);
+/* 0 = GlobalResponseNorm always through the grn_from_partials finalize launch (A/B of the in-GEMM statistics of the batch-1 path); 1 = default */
+int paella_test_grn_fuse(int on);
 /* Measurement hook (bench.py roofline line): when enabled, EVERY dense-contraction launch (the head GEMM with the fused sampling tail included)
  * is bracketed by HIP events on its stream; collect() returns the summed duration, algorithmic FLOPs and bytes since enable(1).  Process-wide,
  * single host thread (the events live in a plain vector). */
 int paella_prof_enable(int on);
-int paella_prof_collect(double* total_ms, double* total_flops, double* total_bytes, long long* launches);
+int paella_prof_collect(double* total_ms, double* total_flops, double* total_bytes, int64_t* launches);
 /* per-launch records since enable(1), not reset (call before collect): us_out[i], shape_out[5 i ..] = M, N, K, prologue (0 none, 1 GRN, 2 LayerNorm,
  * 3 implicit convolution), fused-tail flag; returns the launch count (at most cap are written) */
 long long paella_prof_detail(float* us_out, int* shape_out, long long cap);
 /* scores_out [rows, L] = the Gumbel-max scores of the counter-based sampling tail (mix(l_c, l_u) / T - log q, the kernels' own arithmetic and
  * Philox counters): tests classify a differing token by the decision margin between the two best scores of its row */
-int paella_test_tail_scores(const float* logits_c, const float* logits_u, long long rows, int L, float cfg, float one_minus_cfg, float temperature,
-                            unsigned long long seed, unsigned long long offset, long long row_offset, float* scores_out, void* stream);
+int paella_test_tail_scores(const float* logits_c, const float* logits_u, int64_t rows, int L, float cfg, float one_minus_cfg, float temperature,
+                            uint64_t seed, uint64_t offset, int64_t row_offset, float* scores_out, void* stream);
 #ifdef __cplusplus
 }
 #endif

@@ -99,16 +99,26 @@ def _pack_seed(seed, device):
     return torch.tensor([int(seed)], dtype=torch.int64).view(torch.float32).to(device)
 
 
-def broadcast_conditioning(input_sets, src=0, device=None, group=None, layout=None, seed=None, with_seed=False):
+def broadcast_conditioning(input_sets, src=0, device=None, group=None, layout=None, seed=None, with_seed=False, seed_on_device=False, validate=None):
     """Broadcast a list of conditioning dicts (e.g. [model_inputs, unconditional_inputs]) from `src` with ONE
     tensor collective.  Non-source ranks pass None.  Without `layout` the shapes travel first in one small object
     broadcast (which synchronises host and device; a receiver cannot size its buffer otherwise); with `layout` =
     conditioning_layout(...) / cond_spec_layout(...) known on every rank the call is a single asynchronous RCCL broadcast on
     the current stream.  with_seed=True appends the source's Philox seed (`seed`, or a fresh one) to the SAME buffer and
-    returns (sets, seed): seed agreement costs no collective of its own."""
+    returns (sets, seed): seed agreement costs no collective of its own.  seed_on_device=True returns the seed as a 1-element
+    int64 DEVICE tensor (pass it as sample(..., seed=0, seed_dev=t)): no host synchronisation at all on the layout path;
+    otherwise the seed is read back with .item() (one host-device sync per call).
+    A conditioning that does not match the agreed `layout` can only be detected on the source.  It never enters the collective
+    with a wrong-sized buffer (the other ranks would block forever): the source sends a buffer of the AGREED size whose trailing
+    flag word is 0 and whose payload is NaN, then raises ValueError; receivers raise too when validate=True (default on the
+    handshake path, which synchronises anyway; on the layout path it costs one host sync, so it defaults to False there and a
+    receiver of a poisoned buffer computes NaN-conditioned output instead of hanging)."""
     rank = dist.get_rank(group)
     meta = [None]
     flat = None
+    bad = False
+    if validate is None:
+        validate = layout is None
     if rank == src:
         all_tensors, descs = [], []
         for s in input_sets:
@@ -119,25 +129,33 @@ def broadcast_conditioning(input_sets, src=0, device=None, group=None, layout=No
         flat = torch.cat([t.reshape(-1).float() for t in all_tensors]).to(device) if all_tensors else torch.zeros(0, device=device)
         meta = [(descs, flat.numel())]
         if layout is not None and (layout[1] != flat.numel() or [list(map(tuple, d)) for d in layout[0]] != [list(map(tuple, d)) for d in descs]):
-            raise ValueError("conditioning does not match the agreed layout")
+            bad = True  # keep the collective well-formed: agreed size, poisoned payload, flag 0
+            flat = torch.full((layout[1],), float("nan"), dtype=torch.float32, device=device)
         if with_seed:
             if seed is None:
                 from .sampling import fresh_seed
                 seed = fresh_seed()
             flat = torch.cat([flat, _pack_seed(seed, flat.device)])
+        flat = torch.cat([flat, torch.tensor([0.0 if bad else 1.0], dtype=torch.float32, device=flat.device)])
     if layout is None:
         dist.broadcast_object_list(meta, src=src, group=group)
         descs, numel = meta[0]
     else:
         descs, numel = layout
+    extra = (2 if with_seed else 0) + 1
     if rank != src:
         if device is None:
             raise ValueError("non-source ranks must pass device")
-        flat = torch.empty(numel + (2 if with_seed else 0), dtype=torch.float32, device=device)
+        flat = torch.empty(numel + extra, dtype=torch.float32, device=device)
     dist.broadcast(flat, src=src, group=group)
+    if bad:
+        raise ValueError("conditioning does not match the agreed layout (a poisoned buffer of the agreed size was broadcast so that no rank blocks)")
+    if validate and float(flat[numel + extra - 1].item()) != 1.0:
+        raise ValueError("the source rank's conditioning did not match the agreed layout")
     if with_seed:
-        seed = int(flat[numel:numel + 2].clone().view(torch.int64).item())
-        flat = flat[:numel]
+        seed_t = flat[numel:numel + 2].clone().view(torch.int64)  # 1-element int64 tensor on the buffer's device
+        seed = seed_t if seed_on_device else int(seed_t.item())
+    flat = flat[:numel]
     out, off = [], 0
     for d in descs:
         n = 0
@@ -197,15 +215,15 @@ def sample_sharded(model, model_inputs, unconditional_inputs, latent_shape, src=
     device = next(model.parameters()).device
     philox = noise == "philox"
     res = broadcast_conditioning([model_inputs, unconditional_inputs] if rank == src else None, src=src, device=device, group=group,
-                                 layout=layout, seed=seed, with_seed=philox)
-    (cond, uncond), seed = res if philox else (res, seed)
+                                 layout=layout, seed=seed, with_seed=philox, seed_on_device=philox)
+    (cond, uncond), seed_dev = res if philox else (res, None)  # the seed stays on the device: no host sync between the broadcast and the sampler
     B, H, W = latent_shape
     lo, hi = shard_bounds(B, rank, world)
     shard = (lo, B) if philox else None
     local = None
     if hi > lo:
         local = sample(model, shard_inputs(cond, lo, hi), (hi - lo, H, W), unconditional_inputs=shard_inputs(uncond, lo, hi),
-                       device=device, noise=noise, seed=seed, shard=shard, **kwargs)
+                       device=device, noise=noise, seed=0 if philox else seed, seed_dev=seed_dev, shard=shard, **kwargs)
     if not gather:
         return local
     sizes = [shard_bounds(B, r, world) for r in range(world)]

@@ -149,7 +149,7 @@ def _sample_core(model, model_inputs, unconditional_inputs, latent_shape, init_x
         elif explicit:
             init_noise = noise["init_noise"].to(device=device, dtype=torch.int64).contiguous()
         elif philox:
-            init_noise = start_tokens(L, (B, H, W), seed, device, shard)
+            init_noise = start_tokens(L, (B, H, W), seed, device, shard, seed_dev=seed_dev, row_offset_dev=row_offset_dev)
         else:
             init_noise = torch.randint(0, L, size=(B, H, W), device=device)
         sampled = init_noise.clone() if init_x is None else init_x.to(device=device, dtype=torch.int64).contiguous()
@@ -232,13 +232,14 @@ def _sample_core(model, model_inputs, unconditional_inputs, latent_shape, init_x
 
 
 def sample(model, model_inputs, latent_shape, unconditional_inputs=None, steps=12, renoise_steps=11, temperature=(1.0, 0.2),
-           cfg=8.0, t_start=1.0, t_end=0.0, device="cuda", *, noise="torch", seed=None, attn_weights=None, shard=None, fused_tail=True):
+           cfg=8.0, t_start=1.0, t_end=0.0, device="cuda", *, noise="torch", seed=None, seed_dev=None, attn_weights=None, shard=None, fused_tail=True):
     """Drop-in for reference src/utils.py:35 `sample` (same positional order and defaults).
     Keyword-only extensions: noise ("torch" = consume torch's generator exactly like the reference; "philox" = counter-based
     noise generated in the kernels, keyed by `seed` -- None draws a fresh seed from torch's generator), attn_weights
     (utils/modules.py:268), shard=(lo, total) for batch-sharded sampling (paella_amd.dist.sample_sharded), fused_tail (counter-based
     mode only: take the categorical decision inside the head GEMM so the logits are never written; False keeps the two-kernel
-    path -- same tokens bit for bit, for A/B measurements)."""
+    path -- same tokens bit for bit, for A/B measurements), seed_dev (counter-based mode: a 1-element int64 DEVICE tensor added to `seed` inside
+    the kernels -- a seed that arrived in a collective is used without a host round trip; pass seed=0 with it)."""
     if cfg and unconditional_inputs is None:
         # the reference raises TypeError at src/utils.py:46 (`**None`); keep the failure, make it readable
         raise TypeError("cfg=%r requires unconditional_inputs" % (cfg,))
@@ -251,7 +252,7 @@ def sample(model, model_inputs, latent_shape, unconditional_inputs=None, steps=1
     else:
         cfgs = [None] * steps
     return _sample_core(model, model_inputs, unconditional_inputs, latent_shape, None, steps, renoise_steps, t_list, temperatures,
-                        cfgs, device, noise=noise, seed=seed, attn_weights=attn_weights, shard=shard, fused_tail=fused_tail)
+                        cfgs, device, noise=noise, seed=seed, seed_dev=seed_dev, attn_weights=attn_weights, shard=shard, fused_tail=fused_tail)
 
 
 def sample_distributed(model, model_inputs, unconditional_inputs, latent_shape, init_x=None, steps=12, renoise_steps=None,

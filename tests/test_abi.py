@@ -55,3 +55,14 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in text and "from oracle" not in text, f
+
+
+def test_stale_library_is_refused(built_lib, monkeypatch):
+    """The library carries the hash of the sources it was built from (paella_source_stamp); the binding recomputes it from the tree and refuses a
+    library built from other sources instead of benchmarking it silently (build.py trusted modification times)."""
+    from paella_amd import _lib, _stamp, build
+    assert built_lib.paella_source_stamp().decode() == _stamp.source_stamp() == build.built_stamp()
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_stamp, "source_stamp", lambda: "0" * 32)
+    with pytest.raises(_lib.PaellaHipError, match="built from other sources"):
+        _lib.load()

@@ -81,8 +81,12 @@ def _shard_worker(rank, world, port, q):
         from paella_amd.dist import sample_sharded
         calls = []
 
-        def fake_sample(model, model_inputs, latent_shape, unconditional_inputs=None, device=None, noise=None, seed=None, shard=None, **kw):
-            # stands in for the HIP sampler: a pure function of (seed, GLOBAL row), exactly the contract the Philox kernels keep
+        def fake_sample(model, model_inputs, latent_shape, unconditional_inputs=None, device=None, noise=None, seed=None, seed_dev=None, shard=None, **kw):
+            # stands in for the HIP sampler: a pure function of (seed, GLOBAL row), exactly the contract the Philox kernels keep.  The seed that
+            # arrived in the conditioning broadcast stays a device tensor (`seed_dev`, added to `seed` inside the kernels): no host sync in the product
+            if seed_dev is not None:
+                assert seed_dev.dtype == torch.int64 and seed_dev.numel() == 1
+                seed = int(seed) + int(seed_dev.item())
             calls.append((tuple(latent_shape), seed, shard, model_inputs["clip"].clone(), unconditional_inputs["clip"].clone()))
             B, H, W = latent_shape
             pos = torch.arange(shard[0] * H * W, (shard[0] + B) * H * W).view(B, H, W)   # GLOBAL position index

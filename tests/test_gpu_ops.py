@@ -30,6 +30,13 @@ def _check(lib, rc):
     assert rc == 0, lib.paella_last_error()
 
 
+def _ln_partials(blk):
+    """What a producing GEMM's epilogue leaves per row and 16-column block (Epilogue::rowstat_out): (sum, M2 = sum of squared deviations from the block mean)."""
+    blk = blk.float()
+    s = blk.sum(-1)
+    return torch.stack([s, ((blk - (s / 16)[..., None]) ** 2).sum(-1)], dim=-1).contiguous()
+
+
 GEMM_SHAPES = [(512, 2560, 640), (512, 640, 2560), (128, 5120, 1280), (128, 1280, 5120), (32, 3840, 1280), (32, 1280, 1280),
                (1, 4096, 1024), (2, 1024, 48), (1024, 8192, 256), (1024, 384, 4), (77, 132, 36), (300, 12, 96), (16, 64, 2048)]
 
@@ -50,7 +57,7 @@ def test_gemm_heuristic(lib, M, N, K):
     np.testing.assert_allclose(C.cpu().numpy(), ref.numpy(), atol=2e-5 * max(1, K ** 0.5 / 8), rtol=1e-5)
 
 
-N_TILE_CONFIGS = 36  # paella_amd/csrc/gemm.hip kCfgs (30..35: the LDS-DMA ring tiles of the batch-1 path)
+N_TILE_CONFIGS = 37  # paella_amd/csrc/gemm.hip kCfgs (30..35: the LDS-DMA ring tiles of the batch-1 path; 36: the 256x128 throughput-regime tile)
 
 
 @pytest.mark.parametrize("cfg", range(N_TILE_CONFIGS))
@@ -86,7 +93,7 @@ def test_gemm_operand_prologues_every_tile_config(lib, cfg, mode, splitk):
     scale = 1.0 + 0.3 * torch.randn(B, K, generator=g)
     shift = 0.2 * torch.randn(K, generator=g)
     blk = A.view(M, K // 16, 16)
-    stats = torch.stack([blk.sum(-1), (blk * blk).sum(-1)], dim=-1).contiguous()
+    stats = _ln_partials(blk)
     if mode == 1:
         a2 = A.double() * scale.double().repeat_interleave(rps, dim=0) + shift.double()
     else:
@@ -98,6 +105,73 @@ def test_gemm_operand_prologues_every_tile_config(lib, cfg, mode, splitk):
     _check(lib, lib.paella_test_gemm_prologue(_p(Ad), _p(Wd), _p(C), M, N, K, mode, _p(sc), _p(sh), rps, _p(sd), cfg, splitk, _p(ws), ws.numel(), _st()))
     torch.cuda.synchronize()
     np.testing.assert_allclose(C.cpu().numpy(), ref.numpy(), atol=2e-4, rtol=2e-5)
+
+
+LN_RATIOS = [0.0, 1.0, 10.0, 30.0, 100.0, 1000.0]
+
+
+def _ln_case(ratio, outliers, M=200, N=168, K=1280, seed=0):
+    g = torch.Generator().manual_seed(seed + int(ratio) * 7 + outliers)
+    A = torch.randn(M, K, generator=g)
+    if outliers:  # a few channels far outside the rest in every row ("massive activation" channels of released checkpoints)
+        A[:, [3, 400, 911]] += torch.tensor([60.0, -45.0, 80.0])
+    A = A * (1.0 + 0.5 * torch.rand(M, 1, generator=g))        # per-row scale
+    A = A + ratio * A.std(dim=1, keepdim=True) * torch.sign(torch.randn(M, 1, generator=g))  # row mean = +-ratio row std (on top of the outliers' own mean)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    ref = (F.layer_norm(A.double(), (K,), None, None, 1e-6) @ W.double().t())
+    return A, W, ref
+
+
+@pytest.mark.parametrize("cfg,splitk", [(5, 1), (5, 3), (18, 1), (10, 1), (26, 1), (30, 1), (30, 5), (31, 1), (34, -50), (36, 1), (36, 2)])
+def test_layernorm_fold_error_bound_vs_row_mean(lib, cfg, splitk):
+    """LayerNorm folded into the consuming GEMM (reference src/modules.py:22-27 ahead of a Linear): the epilogue form rstd * (acc - mu * wsum[n]) cancels when a
+    row's |mean| >> std, so 16-row blocks above |mean| / std = 4 normalise their operand fragments instead, and the row statistics come from CENTRED
+    per-block partials.  STATED BOUND: max |out - fp64| <= 6e-5 on outputs of unit scale for |mean| / std up to 1000, with or without
+    outlier channels, on every tile class (register-staged, direct-to-LDS, 8-wave pipelined, ring, 256x128) and with split K."""
+    ws = _lib.new_workspace(128 << 20, "cuda")
+    rows = []
+    for outliers in (0, 1):
+        for ratio in LN_RATIOS:
+            A, W, ref = _ln_case(ratio, outliers)
+            M, K = A.shape
+            N = W.shape[0]
+            sd = _ln_partials(A.cuda().view(M, K // 16, 16))  # fp32 partials, as the producing epilogue computes them
+            Ad, Wd = A.cuda(), W.cuda()
+            C = torch.full((M, N), float("nan"), device="cuda")
+            _check(lib, lib.paella_test_gemm_prologue(_p(Ad), _p(Wd), _p(C), M, N, K, 2, None, None, 1, _p(sd), cfg, splitk, _p(ws), ws.numel(), _st()))
+            torch.cuda.synchronize()
+            err = float((C.cpu().double() - ref).abs().max())
+            rows.append((outliers, ratio, err))
+    print("cfg %d splitk %d: " % (cfg, splitk) + "  ".join("%s|mu|/std=%g: %.1e" % ("outl " if o else "", r, e) for o, r, e in rows))
+    assert max(e for _, _, e in rows) <= 6e-5, rows
+
+
+@pytest.mark.parametrize("cfg", [18, 30, 36])
+def test_layernorm_fold_without_the_guard_loses_digits(lib, cfg):
+    """The measurement behind the guard: with the threshold moved to infinity (test hook) the fold's error grows ~ linearly with |mean| / std; with the
+    threshold at 0 (always operand-side) it does not.  Printed for profiles/r04_ln_fold_error_curve.txt."""
+    ws = _lib.new_workspace(128 << 20, "cuda")
+    out = {}
+    try:
+        for name, thr in (("fold always", float("inf")), ("operand-side always", 0.0), ("guarded (4)", 4.0)):
+            lib.paella_test_ln_fold_ratio(thr)
+            errs = []
+            for ratio in LN_RATIOS:
+                A, W, ref = _ln_case(ratio, 0)
+                M, K = A.shape
+                N = W.shape[0]
+                sd = _ln_partials(A.cuda().view(M, K // 16, 16))
+                Ad, Wd = A.cuda(), W.cuda()
+                C = torch.full((M, N), float("nan"), device="cuda")
+                _check(lib, lib.paella_test_gemm_prologue(_p(Ad), _p(Wd), _p(C), M, N, K, 2, None, None, 1, _p(sd), cfg, 1, _p(ws), ws.numel(), _st()))
+                torch.cuda.synchronize()
+                errs.append(float((C.cpu().double() - ref).abs().max()))
+            out[name] = errs
+            print("cfg %d %-20s " % (cfg, name) + "  ".join("%g: %.1e" % (r, e) for r, e in zip(LN_RATIOS, errs)))
+    finally:
+        lib.paella_test_ln_fold_ratio(4.0)
+    assert out["fold always"][-1] > 20 * out["operand-side always"][-1]       # the cancellation is real ...
+    assert max(out["guarded (4)"]) <= 6e-5 and max(out["operand-side always"]) <= 6e-5  # ... and the guard removes it
 
 
 @pytest.mark.parametrize("B,rps,c", [(2, 64, 1280), (2, 16, 1280), (1, 64, 64), (3, 16, 96), (5, 64, 32), (4, 16, 32)])
@@ -149,7 +223,7 @@ def test_gemm_direct_to_lds_twin_is_bit_identical(lib, cfg, mode, splitk):
     W = torch.randn(N, K, generator=g) / K ** 0.5 + torch.arange(N)[:, None] * 0.002
     scale, shift = 1.0 + 0.3 * torch.randn(B, K, generator=g), 0.2 * torch.randn(K, generator=g)
     blk = A.view(M, K // 16, 16)
-    stats = torch.stack([blk.sum(-1), (blk * blk).sum(-1)], dim=-1).contiguous()
+    stats = _ln_partials(blk)
     Ad, Wd, sc, sh, sd = A.cuda(), W.cuda(), scale.cuda(), shift.cuda(), stats.cuda()
     ws = _lib.new_workspace(64 << 20, "cuda")
     outs = []
@@ -169,7 +243,7 @@ def test_gemm_direct_to_lds_twin_is_bit_identical(lib, cfg, mode, splitk):
 
 
 @pytest.mark.parametrize("cfg,G", [(5, 512), (11, 512), (12, 256), (12, 509), (13, 768), (14, 256), (16, 256), (22, 640), (9, 300), (2, 1000), (24, 512), (25, 777), (26, 100), (29, 64),
-                                   (30, 512), (30, 1280), (31, 777), (32, 300), (33, 301), (34, 100), (35, 64)])
+                                   (30, 512), (30, 1280), (31, 777), (32, 300), (33, 301), (34, 100), (35, 64), (36, 7), (36, 64), (36, 200)])
 def test_gemm_stream_k_is_repeatable(lib, cfg, G):
     """Balanced unit ranges (partial tiles combined by the last arriver in fixed part order): many back-to-back launches on
     one workspace give bit-identical, correct results -- tickets re-arm, slabs are re-used, no stale reads."""
@@ -190,11 +264,45 @@ def test_gemm_stream_k_is_repeatable(lib, cfg, G):
     assert all(torch.equal(outs[0], o) for o in outs[1:])
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("M", [1000, 2304])
+def test_gemm_big_tile_matches_the_64x64_tile(lib, mode, M):
+    """The 256x128 throughput-regime tile (id 36: 8 waves, 3-stage LDS-DMA ring, fragments read a k group ahead, GRN applied to the fragments)
+    multiplies in the same k order as every other tile: with one tile per workgroup its result equals the 64x64 direct-to-LDS tile's (id 18)
+    BIT FOR BIT for plain and LayerNorm-folded operands, ragged M / N, several tiles per workgroup column; the GRN prologue (transform applied to
+    the fragments instead of at staging) is compared against fp64 as well."""
+    rps, N, K = 40, 392, 736  # K % 32 == 0; samples straddle the 256-row tiles (7 samples per tile)
+    B = M // rps
+    M = B * rps
+    g = torch.Generator().manual_seed(M + mode)
+    A = torch.randn(M, K, generator=g) + torch.arange(K)[None, :] * 0.01
+    W = torch.randn(N, K, generator=g) / K ** 0.5 + torch.arange(N)[:, None] * 0.002
+    scale, shift = 1.0 + 0.3 * torch.randn(B, K, generator=g), 0.2 * torch.randn(K, generator=g)
+    blk = A.view(M, K // 16, 16)
+    stats = _ln_partials(blk)
+    Ad, Wd, sc, sh, sd = A.cuda(), W.cuda(), scale.cuda(), shift.cuda(), stats.cuda()
+    ws = _lib.new_workspace(128 << 20, "cuda")
+    outs = {}
+    for cfg, sk in ((36, 1), (18, 1), (36, -20)):
+        C = torch.full((M, N), float("nan"), device="cuda")
+        _check(lib, lib.paella_test_gemm_prologue(_p(Ad), _p(Wd), _p(C), M, N, K, mode, _p(sc), _p(sh), rps, _p(sd), cfg, sk, _p(ws), ws.numel(), _st()))
+        torch.cuda.synchronize()
+        outs[(cfg, sk)] = C
+    a2 = A.double() if mode == 0 else (A.double() * scale.double().repeat_interleave(rps, dim=0) + shift.double() if mode == 1 else F.layer_norm(A.double(), (K,), None, None, 1e-6))
+    ref = (a2 @ W.double().t()).float().numpy()
+    for k, C in outs.items():
+        np.testing.assert_allclose(C.cpu().numpy(), ref, atol=2e-3, rtol=2e-5, err_msg=str(k))
+    if mode != 1 or torch.equal(outs[(36, 1)], outs[(18, 1)]):
+        assert torch.equal(outs[(36, 1)], outs[(18, 1)])
+    else:  # fragment-level vs staging-time GRN apply: same fp32 expression, the compiler may contract it differently
+        print("GRN prologue: 256x128 tile vs 64x64 tile max |diff| %.3e" % float((outs[(36, 1)] - outs[(18, 1)]).abs().max()))
+
+
 def test_gemm_stream_k_multi_m_tiles_and_tails(lib):
     """Ranges that cross tiles in both directions (several M tiles per weight panel, K tail, ragged M / N)."""
     g = torch.Generator().manual_seed(3)
     for (M, N, K, cfg, G) in [(500, 200, 1000, 2, 37), (300, 520, 36, 5, 100), (129, 68, 4100, 11, 17), (257, 300, 644, 12, 33),
-                              (40, 4096, 100, 22, 200), (1000, 72, 260, 9, 9)]:
+                              (40, 4096, 100, 22, 200), (1000, 72, 260, 9, 9), (1000, 300, 640, 36, 9), (700, 260, 2048, 36, 61), (515, 132, 96, 36, 5)]:
         A = torch.randn(M, K, generator=g) + torch.arange(K)[None, :] * 0.01
         W = torch.randn(N, K, generator=g) / 30 + torch.arange(N)[:, None] * 0.002
         ref = (A.double() @ W.double().t()).float()

@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--raster", type=int, default=None, help="tile rows per rasterisation group (test hook; 0 = plain m-fastest order)")
     ap.add_argument("--copies", type=int, default=0, help="rotate over exactly this many weight copies (2-3 = the weights stay in the 256 MiB Infinity Cache: "
                     "the upper bound of what a weight prefetch could buy); default: enough copies to exceed it (cold weights, as in the model)")
+    ap.add_argument("--act", type=int, default=0, help="1 = bias + GELU(erf) epilogue (the MLP's first GEMM)")
     ap.add_argument("--cfgs", default=None, help="comma-separated tile configs to sweep (default: all that fit)")
     a = ap.parse_args()
     lib = _lib.load()
@@ -74,6 +75,7 @@ def main():
             ncopy = a.copies
         A = torch.randn(M, K, device="cuda")
         Ws = [torch.randn(N, K, device="cuda") for _ in range(ncopy)]
+        bias = torch.randn(N, device="cuda") if a.act else None
         C = torch.empty(M, N, device="cuda")
         rps = 64 if M % 64 == 0 else 16
         scale = torch.ones(M // rps, K, device="cuda")
@@ -86,7 +88,7 @@ def main():
                    9: (128, 128), 10: (128, 128), 11: (128, 32), 12: (128, 64), 13: (64, 64), 14: (128, 64), 15: (256, 32), 16: (256, 64),
                    17: (128, 64), 18: (64, 64), 19: (32, 32), 20: (128, 64), 21: (64, 32), 22: (32, 128), 23: (32, 64),
                    24: (32, 32), 25: (32, 32), 26: (64, 64), 27: (128, 32), 28: (32, 64), 29: (128, 64),
-                   30: (32, 32), 31: (32, 32), 32: (32, 64), 33: (64, 32), 34: (64, 64), 35: (32, 64)}  # 30..35: LDS-DMA ring tiles
+                   30: (32, 32), 31: (32, 32), 32: (32, 64), 33: (64, 32), 34: (64, 64), 35: (32, 64), 36: (256, 128)}  # 30..35: LDS-DMA ring tiles; 36: 256x128 on 8 waves
         bk_of = {c: (64 if 24 <= c <= 29 else 32) for c in tile_of}
         def fits(c):  # skip tiles that waste more than half their rows on this M
             bm = tile_of[c][0]
@@ -97,9 +99,11 @@ def main():
         if a.big_only:
             variants = [(-1, 1)] + [(c, 1) for c in (0, 1, 2, 9, 10, 12, 14, 16, 18)]
         if M >= 4096:  # MFMA-bound: no split-K, few candidates, few iterations
-            big = (0, 1, 2, 9, 10, 12, 14, 16, 18) + tuple(c for c in (32, 33, 34) if a.cfgs and str(c) in a.cfgs.split(","))
+            big = (0, 1, 2, 9, 10, 12, 14, 16, 18, 36) + tuple(c for c in (32, 33, 34) if a.cfgs and str(c) in a.cfgs.split(","))
+            if a.cfgs:
+                big = tuple(c for c in big if str(c) in a.cfgs.split(","))
             variants = [(-1, 1)] + [(c, 1) for c in big] + \
-                       [(c, -G) for c in (2, 10, 14, 18) + tuple(c for c in big if c >= 30) for G in (256, 512, 768, 1024)]
+                       [(c, -G) for c in big if c in (2, 10, 14, 18) or c >= 30 for G in ((256, 512) if c == 36 else (256, 512, 768, 1024))]
         for cfg, sk in variants:
             if sk > 1 and K // sk < 96:
                 continue
@@ -113,7 +117,7 @@ def main():
                 if a.apro:
                     return lib.paella_test_gemm_prologue(A.data_ptr(), W.data_ptr(), C.data_ptr(), M, N, K, a.apro, scale.data_ptr(), shift.data_ptr(), rps,
                                                          stats.data_ptr(), cfg, sk, ws.data_ptr(), ws.numel(), st())
-                return lib.paella_op_gemm(A.data_ptr(), W.data_ptr(), None, None, C.data_ptr(), M, N, K, 0, cfg, sk, ws.data_ptr(), ws.numel(), st())
+                return lib.paella_op_gemm(A.data_ptr(), W.data_ptr(), bias.data_ptr() if a.act else None, None, C.data_ptr(), M, N, K, a.act, cfg, sk, ws.data_ptr(), ws.numel(), st())
             if run(Ws[0]) != 0:
                 continue
             ts = []
