@@ -122,6 +122,7 @@ struct GemmArgs {
     const float* ln_stats;
     int ln_nblk;
     float ln_eps;
+    const float* ln_row;       // optional [M, 4]: the rows' FINISHED statistics (mean, rstd, mean - (float)mean, |mean| * rstd) from launch_ln_rowstat_finalize -- set by the launcher in the throughput regime
     float ln_fold_ratio;       // 16-row blocks with |mean| * rstd above this normalise their operand fragments instead of using the fold (set by launch_gemm_cfg)
     const float* ln_wsum;      // [N]: sum_k W[n][k] -- the LayerNorm is folded into the epilogue as rstd * (acc - mean * wsum[n]) (gemm.hip: ln_row_stats)
     Epilogue ep;
@@ -156,6 +157,9 @@ int launch_gemm_bf16(const GemmArgs& g, int tile, int splitk, void* ws, size_t w
 int gemm_register_weight(const float* base, size_t numel, hipStream_t stream);
 void gemm_unregister_weight(const float* base);
 int gemm_precision();
+
+// ln_stats [M, nblk, 2] (per 16-column block (sum, centred M2)) -> out4 [M, 4] = (mean, rstd, mean - (float)mean, |mean| * rstd)
+int launch_ln_rowstat_finalize(const float* stats, int nblk, int K, float eps, float* out4, int64_t M, hipStream_t stream);
 
 // LayerNorm over the channel dimension of [rows, C]; no learned affine (eps 1e-6),
 // optional scalar affine y = ln(x)*(1+g0)+g1 (VQGAN), optional space-to-depth gather:

@@ -3,6 +3,7 @@
 // ([rows = B*h*w, C] row-major), so every wave streams whole channel rows with 16-byte lanes and all
 // per-position reductions are wave64 shuffles (no LDS, no barriers) -- one wave per position.
 #include "common.h"
+#include "gemm_device.h"
 
 #define WAVES_PER_BLOCK 4
 
@@ -95,6 +96,34 @@ int launch_layernorm(const float* x, float* y, int64_t rows, int C, float eps, f
     const unsigned blocks = (unsigned)((rows + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
     DISPATCH_NV(C >> 2, hipLaunchKernelGGL((layernorm_kernel<NV>), dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, st, x, y,
                                            rows, C, eps, g_mul, g_add, s2d, H, W));
+    LAUNCH_CHECK_RET();
+    return PAELLA_OK;
+}
+
+// Row statistics of a LayerNorm-consuming GEMM, finished ONCE per row instead of once per workgroup: from the producing epilogue's per-16-column
+// (sum, centred M2) partials (gemm_device.h) to out[row] = (mean, rstd, mean - (float)mean, |mean| * rstd).  Used for the throughput regime
+// (thousands of rows: every one of the N / 64 workgroups of a tile row would otherwise re-derive the same 64 rows in its ramp -- LayerNorm-consuming
+// GEMMs ran 8-10 % behind plain ones); the batch-1 launches keep the in-kernel derivation (an extra launch costs more than it saves there).
+// 16 lanes per row, fp64 combination, fixed order.
+__global__ __launch_bounds__(256) void ln_rowstat_finalize_kernel(const float* __restrict__ stats, int nblk, int K, float eps, f32x4* __restrict__ out, int64_t M) {
+    const int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int l16 = threadIdx.x & 15;
+    if (row >= M) return;
+    const float* st = stats + (size_t)row * nblk * 2;
+    RowStatAcc acc;
+    for (int j = l16; j < nblk; j += 16) acc.add(st[2 * j], st[2 * j + 1]);
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) { acc.S += __shfl_xor(acc.S, o, 64); acc.Q += __shfl_xor(acc.Q, o, 64); acc.M += __shfl_xor(acc.M, o, 64); }
+    if (l16 == 0) {
+        float mu, rs;
+        acc.finish(K, eps, mu, rs);
+        out[row] = f32x4{mu, rs, (float)(acc.S / (double)K - (double)mu), fabsf(mu) * rs};
+    }
+}
+
+int launch_ln_rowstat_finalize(const float* stats, int nblk, int K, float eps, float* out4, int64_t M, hipStream_t st) {
+    if (M <= 0) return PAELLA_OK;
+    hipLaunchKernelGGL(ln_rowstat_finalize_kernel, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, st, stats, nblk, K, eps, reinterpret_cast<f32x4*>(out4), M);
     LAUNCH_CHECK_RET();
     return PAELLA_OK;
 }

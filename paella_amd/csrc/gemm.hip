@@ -281,6 +281,17 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (WM * WN == 8 ? 1 : TM * T
             // block as a pair) and xor-reduce; combined in fp64 (RowStatAcc)
             int ln_tm, ln_tn;
             sk_tile_coords<(BM >= 64)>(p, ln_tile0, ln_tm, ln_tn);
+            if (g.ln_row) {  // finished once per row by launch_ln_rowstat_finalize (throughput regime): one 16-byte load per fragment row
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int gmc = min(ln_tm * BM + (wm * TM + i) * 16 + r16, g.M - 1);
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(g.ln_row + (size_t)gmc * 4);
+                    fr_mu[i] = v[0]; fr_rs[i] = v[1]; fr_mu_lo[i] = v[2];
+                    ln_dir[i] = __builtin_amdgcn_ballot_w64(v[3] > g.ln_fold_ratio) != 0;
+                    ln_any = ln_any || ln_dir[i];
+                }
+                return;
+            }
             const int nch = g.ln_nblk >> 1;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -528,6 +539,7 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (WM * WN == 8 ? 1 : TM * T
             float* s_score = smem + FLAG_OFF + 16;
             int* s_idx = reinterpret_cast<int*>(s_score + BM * WN);
             const int tile_n_id = n0 / BN;
+            const float inv_t = tail_inv_temperature(ft.temperature);
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int mrow = (wm * TM + i) * 16 + r16;  // row inside the tile
@@ -541,12 +553,18 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (WM * WN == 8 ? 1 : TM * T
                         const f32x4 v = epilogue_apply(g.ep, g.N, m, nn, acc[i][j]);
                         if (ft.mode == 1) {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) argmax_update(best, best_i, v[e], nn + e);
+                            for (int e = 0; e < 4; ++e)
+                                if (v[e] > best) { best = v[e]; best_i = nn + e; }
                         } else {
                             uint32_t rb[4];
                             philox4x32(seed, (uint64_t)(m + row_off) * L4 + (nn >> 2), ft.offset, rb);
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) argmax_update(best, best_i, tail_score_gumbel(v[e], ft.temperature, log_exp1(rb[e])), nn + e);
+                            for (int e = 0; e < 4; ++e) {
+                                // labels are visited in increasing order inside a lane, so "first index wins ties" is a strict comparison here (one compare + two
+                                // selects per logit instead of the general rule's three compares); the cross-lane merges below keep the general rule
+                                const float sc = tail_score_gumbel(v[e], inv_t, log_exp1(rb[e]));
+                                if (sc > best) { best = sc; best_i = nn + e; }
+                            }
                         }
                     }
                 }
@@ -935,26 +953,21 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (WM * WN == 8 ? 1 : TM * T
                         fetch_ring(ls);
                         __builtin_amdgcn_sched_barrier(0);
                         big_read(I0{}, cs);
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (pend) {
-                            big_xform(I1{});
-                            mfma_group(I1{}, I0{}, I4{});
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                        big_read(I1{}, cs);
-                        __builtin_amdgcn_sched_barrier(0);
-                    } else {
-                        if (pend) {
-                            big_xform(I1{});
-                            mfma_group(I1{}, I0{}, I4{});
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (pend) {
+                        big_xform(I1{});
+                        mfma_group(I1{}, I0{}, I4{});
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (late) {
                         fetch_ring(ls);
                         __builtin_amdgcn_sched_barrier(0);
                         big_read(I0{}, cs);
-                        big_read(I1{}, cs);
-                        __builtin_amdgcn_sched_barrier(0);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
+                    big_read(I1{}, cs);
+                    __builtin_amdgcn_sched_barrier(0);
                     big_xform(I0{});
                     mfma_group(I0{}, I0{}, I4{});
                     __builtin_amdgcn_sched_barrier(0);
@@ -1258,7 +1271,7 @@ extern "C" int paella_test_gemm_ring(int cfg) {
 }
 // throughput-regime tile (id 36, 256x128 on 8 waves): 0 = never (the round-3 rules: 64x64 / 128x128 tiles), 1 = launches with >= kBigMinTiles tiles of 256x128
 // (one tile per workgroup), 2 = those + the batched mid-size shapes as ONE persistent workgroup per CU on balanced unit ranges.  Test hook for A/B.
-static std::atomic<int> g_gemm_big{2};
+static std::atomic<int> g_gemm_big{0};
 extern "C" int paella_test_gemm_big(int mode) {
     if (mode < 0 || mode > 2) { paella_set_error("big-tile mode must be 0, 1 or 2"); return PAELLA_ERR_ARG; }
     g_gemm_big = mode;
@@ -1478,7 +1491,9 @@ extern "C" int paella_prof_collect(double* total_ms, double* total_flops, double
 
 // `ws` = a split-K region: kGemmTicketBytes of tickets (zero when first handed over, see paella_workspace_init) followed
 // by slab space.  cfg < 0: heuristic.  splitk > 0: G = tiles * splitk (classic split-K); splitk < 0: G = -splitk workgroups.
-static int launch_gemm_cfg_impl(const GemmArgs& g, int cfg, int splitk, void* ws, size_t ws_bytes, hipStream_t st) {
+static const int kLnPrepassMinRows = 2048;  // from here up the LayerNorm row statistics are finished by one small launch instead of by every workgroup
+static int launch_gemm_cfg_impl(const GemmArgs& g_in, int cfg, int splitk, void* ws, size_t ws_bytes, hipStream_t st) {
+    GemmArgs g = g_in;
     if (g.M <= 0 || g.N <= 0) return PAELLA_OK;
     if ((g.K & 3) || (g.N & 3) || (g.lda & 3) || (g.ldw & 3) || (g.ldc & 3 && g.ep.store_mode != STORE_PIXSHUF_NCHW)) {
         paella_set_error("gemm: K, N, lda, ldw, ldc must be multiples of 4 (M=%d N=%d K=%d lda=%d ldw=%d ldc=%d)",
@@ -1507,7 +1522,16 @@ static int launch_gemm_cfg_impl(const GemmArgs& g, int cfg, int splitk, void* ws
         }
     }
     const bool have_ws = ws && ws_bytes > kGemmTicketBytes;
-    const size_t slab_cap = have_ws ? ws_bytes - kGemmTicketBytes : 0;
+    size_t slab_cap = have_ws ? ws_bytes - kGemmTicketBytes : 0;
+    if (g.ln_stats && !g.ln_row && g.M >= kLnPrepassMinRows && gemm_precision() == 0 && slab_cap >= ((size_t)64 << 20) + (size_t)g.M * 16) {
+        // the finished statistics live at the END of the split-K region (the slabs of this launch, if any, start at its front)
+        const size_t bytes = ((size_t)g.M * 16 + 255) & ~(size_t)255;
+        float* row4 = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + ws_bytes - bytes);
+        slab_cap -= bytes;
+        const int rc = launch_ln_rowstat_finalize(g.ln_stats, g.ln_nblk, g.K, g.ln_eps, row4, g.M, st);
+        if (rc != PAELLA_OK) return rc;
+        g.ln_row = row4;
+    }
     unsigned G = 0;
     if (cfg < 0) {
         choose_config(g.M, g.N, g.K, (g.a_scale || g.grn_gx) ? 1 : (g.ln_stats ? 2 : 0), ring_ok(g, 64), ring_ok(g, 256) && !g.grn_gx && !g.ep.grn_gx_out, g.force_ring_cfg, slab_cap, &cfg, &G);
@@ -1653,13 +1677,17 @@ static int launch_gemm_tail_impl(const GemmArgs& g, hipStream_t st) {
     const unsigned long long T = (unsigned long long)p.tiles_m * p.tiles_n;
     if (T * (unsigned long long)p.KT >= (1ull << 31)) { paella_set_error("gemm_tail: problem too large"); return PAELLA_ERR_ARG; }
     p.U = (unsigned)(T * p.KT);
-    // one whole tile per workgroup.  (Persistent workgroups that walk several tiles as one unit stream -- the prefetch ring running into the next tile while
-    // the Philox / log epilogue executes -- were measured neutral in round 3: 19.76 vs 19.75 images/s at configs[2]; not kept.)
+    // One whole tile per workgroup.  Measured and NOT kept (profiles/r04_head_tail_ab.txt): 512 persistent workgroups walking T / 512 tiles each (round 3: neutral),
+    // and the same with the second workgroup of every CU started half a tile period late so that its Philox / log epilogue would run under the other one's main
+    // loop (round 4: 20.21 vs 20.21 images/s at configs[2], 112.9-113.3 at batch 32 for every variant) -- the launch is not limited by phase alignment.
     const unsigned long long G = T;
+    p.stagger = 0;
     p.q = (unsigned)(p.U / G);
     p.r = 0;
-    p.stagger = 0;
-    p.gm = p.tiles_m;
+    // grouped rasterisation as in the unfused launches: with K = c_out = 256 a tile moves 196 KB of operands for 4.2 MFLOP, and in plain m-fastest order no two
+    // tiles that run together share an activation panel -- the whole activation matrix crosses the fabric once per column tile (34 GB per launch at configs[2])
+    const int raster_gm = g_gemm_raster_gm;
+    p.gm = (raster_gm > 0 && BM >= 64 && p.tiles_m >= 4 * raster_gm && p.tiles_n >= 4) ? raster_gm : p.tiles_m;
     if (cfg == 9) hipLaunchKernelGGL((gemm_nt_kernel<4, 2, 2, 4, 1, 0, true>), dim3((unsigned)G), dim3(512), 0, st, g, p, (float*)nullptr, (unsigned*)nullptr, 0u);
     else if (cfg == 14) hipLaunchKernelGGL((gemm_nt_kernel<4, 2, 2, 2, 2, 0, true>), dim3((unsigned)G), dim3(512), 0, st, g, p, (float*)nullptr, (unsigned*)nullptr, 0u);
     else hipLaunchKernelGGL((gemm_nt_kernel<2, 2, 2, 2, 2, 0, true>), dim3((unsigned)G), dim3(256), 0, st, g, p, (float*)nullptr, (unsigned*)nullptr, 0u);

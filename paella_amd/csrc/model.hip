@@ -472,6 +472,7 @@ extern "C" int paella_unet_finalize(paella_unet* m, void* stream) {
 
 // ---------------------------------------------------------------------------
 // conditioning cache layout: ONE row-major matrix [B*S, kv_total]; AttnBlock i (execution order) owns columns [kv_col[i], +2*c_i) = (K | V)
+// (a block-major layout -- one contiguous [B*S, 2c] matrix per AttnBlock -- was tried in round 4: no effect on the attention launch, profiles/r04_attention_launch_ab.txt)
 // ---------------------------------------------------------------------------
 extern "C" size_t paella_unet_cond_bytes(const paella_unet* m, int B, int S) {
     if (!m) return 0;

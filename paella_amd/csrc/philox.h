@@ -39,8 +39,11 @@ __device__ __forceinline__ float u01_half_open(uint32_t bits) { return (float)(b
 __device__ __forceinline__ float log_exp1(uint32_t bits) { return __logf(-__logf(u01_open(bits))); }
 // The score both tails maximise in the counter-based mode.  ONE definition: the fused (GEMM epilogue) and unfused (tail kernel)
 // paths must round identically.  contract(off): no FMA may merge the division's multiply-free result with the subtraction.
-__device__ __forceinline__ float tail_score_gumbel(float logit, float temperature, float log_q) {
-    return __fsub_rn(__fdiv_rn(logit, temperature), log_q);
+// inv_temperature = tail_inv_temperature(T), ONE correctly rounded division per thread instead of one per logit (the counter-based mode promises no bit parity with
+// torch's RNG stream, only fused == unfused, which share this function; the torch-noise parity mode keeps the reference's x / T, tail.hip).
+__device__ __forceinline__ float tail_inv_temperature(float temperature) { return __fdiv_rn(1.0f, temperature); }
+__device__ __forceinline__ float tail_score_gumbel(float logit, float inv_temperature, float log_q) {
+    return __fsub_rn(__fmul_rn(logit, inv_temperature), log_q);
 }
 // first index wins ties (deterministic under any reduction order)
 __device__ __forceinline__ void argmax_update(float& best, int& best_i, float score, int idx) {

@@ -73,6 +73,7 @@ __global__ __launch_bounds__(256) void sample_tail_kernel(TailArgs a) {
     }
 
     // pass 2: best score (first index wins ties)
+    const float inv_t = tail_inv_temperature(a.temperature);  // counter-based mode (philox.h: tail_score_gumbel)
     float best = -INFINITY;
     int best_i = 0x7fffffff;
     for (int i4 = tid; i4 < L4; i4 += 256) {
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256) void sample_tail_kernel(TailArgs a) {
                 x = __fdiv_rn(x, a.temperature);
                 score = __fdiv_rn(expf(__fsub_rn(x, mx)), q[e]);
             } else {          // counter-based noise: the same draw in the log domain (Gumbel-max); identical arithmetic in the
-                score = tail_score_gumbel(x, a.temperature, q[e]);  // head GEMM's fused tail epilogue (gemm.hip)
+                score = tail_score_gumbel(x, inv_t, q[e]);  // head GEMM's fused tail epilogue (gemm.hip)
             }
             argmax_update(best, best_i, score, i4 * 4 + e);
         }
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(256) void tail_scores_kernel(TailArgs a, float* __r
         philox4x32(seed, (uint64_t)(row + row_off) * L4 + i4, a.offset, rb);
         f32x4 s;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) s[e] = tail_score_gumbel(mix_logit(c[e], u[e], a.cfg, a.one_minus_cfg, has_u), a.temperature, log_exp1(rb[e]));
+        for (int e = 0; e < 4; ++e) s[e] = tail_score_gumbel(mix_logit(c[e], u[e], a.cfg, a.one_minus_cfg, has_u), tail_inv_temperature(a.temperature), log_exp1(rb[e]));
         *reinterpret_cast<f32x4*>(scores + row * L + i4 * 4) = s;
     }
 }
