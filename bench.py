@@ -386,7 +386,7 @@ def main():
             "config": {"workload": WORKLOAD_TAG.get((a.model, a.batch, a.grid, a.sample_steps), "custom") + ": Paella 573M-class (stand-in blocks=[4,8,4], %.1fM params), %dx%d tokens = %d px, "
                                    "%d steps, CFG 8.0, CLIP-H-text only (S=4), batch %d per GPU, + VQGAN f8 decode"
                                    % (n_params / 1e6, a.grid, a.grid, a.grid * 8, a.sample_steps, a.batch),
-                       "denoiser": a.model, "images_per_gpu_per_step": a.batch, "images_per_step": total, "token_grid": a.grid, "sample_steps": a.sample_steps,
+                       "images_per_gpu_per_step": a.batch, "images_per_step": total, "token_grid": a.grid, "sample_steps": a.sample_steps,
                        "noise": a.noise, "submission": "hip-graph replay" if use_graph else "eager launches",
                        "parallelism": "batch-shard x%d, one conditioning broadcast per step, shard-exact Philox noise (global-row keyed)" % world,
                        "world_size_observed": (dist.get_world_size() if distributed else 1),

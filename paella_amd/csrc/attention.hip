@@ -17,6 +17,7 @@
 // load is unconditional from a clamped in-bounds row so the next tile's loads are all in flight while the
 // current tile computes (two register sets, software pipelined; batch-1 sampling is latency-bound here).
 #include "common.h"
+#include "test_hooks.h"
 #include <atomic>
 #include <math.h>
 

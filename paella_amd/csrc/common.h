@@ -36,6 +36,29 @@ void paella_set_error(const char* fmt, ...);
         }                                                                            \
     } while (0)
 
+// Division of n < 2^31 by a launch constant d as one multiply-high and one shift (host: fast_div_of): the hardware has no integer divide, and a division by a
+// runtime value costs ~25 dependent instructions through the float reciprocal -- two of them sat in front of every workgroup's FIRST operand fetch
+// (tile = unit / KT, tile_m = tile % tiles_m), which at batch 1 is latency on every one of ~1 000 launches per image.
+// d >= 2: l = ceil(log2 d), mul = ceil(2^(31 + l) / d) < 2^32, n / d = (n * mul) >> (31 + l) exactly for every n < 2^31; d == 1: mul = 0, n passes through.
+struct FastDiv { unsigned mul, shr, pass; };  // pass = 0xffffffff for d == 1 (mul = 0): branch-free identity
+__host__ __device__ __forceinline__ unsigned fast_div(unsigned n, const FastDiv& f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (__umulhi(n, f.mul) + (n & f.pass)) >> f.shr;
+#else
+    return ((unsigned)(((unsigned long long)n * f.mul) >> 32) + (n & f.pass)) >> f.shr;
+#endif
+}
+static inline FastDiv fast_div_of(unsigned d) {
+    FastDiv f = {0u, 0u, 0xffffffffu};
+    if (d <= 1) return f;
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;
+    f.mul = (unsigned)((((unsigned long long)1 << (31 + l)) + d - 1) / d);
+    f.shr = l - 1;
+    f.pass = 0u;
+    return f;
+}
+
 // ---------------------------------------------------------------------------
 // GEMM epilogue description (shared by the GEMM kernel and the split-K reducer)
 // ---------------------------------------------------------------------------
@@ -51,6 +74,7 @@ struct Epilogue {
     const float* ts;        // or null: v = v*(1+ts[b*ts_stride + n]) + ts[b*ts_stride + N + n]
     int ts_stride;          // floats between consecutive samples in ts
     int rows_per_sample;    // rows of this matrix per batch sample (for ts)
+    FastDiv rps_div;        // division by rows_per_sample (filled by the launchers)
     int store_mode;         // STORE_*
     int sH, sW, sC;         // STORE_D2S / PIXSHUF: source grid (rows m=(b,y,x)), channels per segment
     int py, px;             // STORE_D2S: extra output offset (transposed-conv phase)
@@ -69,7 +93,7 @@ struct Epilogue {
 static inline Epilogue make_epilogue() {
     Epilogue e;
     e.bias = nullptr; e.act = ACT_NONE; e.alpha = 1.f; e.residual = nullptr; e.ldr = 0;
-    e.ts = nullptr; e.ts_stride = 0; e.rows_per_sample = 1; e.store_mode = STORE_PLAIN;
+    e.ts = nullptr; e.ts_stride = 0; e.rows_per_sample = 1; e.rps_div.mul = 0; e.rps_div.shr = 0; e.rps_div.pass = 0xffffffffu; e.store_mode = STORE_PLAIN;
     e.sH = e.sW = e.sC = 0; e.py = e.px = 0; e.n_seg_x = 2; e.remap_in = e.remap_out = e.remap_off = 0; e.sumsq_out = nullptr; e.rowstat_out = nullptr;
     e.grn_gx_out = nullptr; e.grn_part_out = nullptr; e.grn_rps = 0; e.grn_np = 0;
     return e;
@@ -110,6 +134,7 @@ struct GemmArgs {
     const float* a_scale;      // [samples, K] or null
     const float* a_shift;      // [K]
     int a_rows_per_sample;
+    FastDiv a_rps_div;         // division by a_rows_per_sample (filled by the launchers)
     // or (ring tiles only) the same apply from the producer's UNFINISHED statistics: a' = a * (1 + gamma[k] * gx[b][k] / (mean_k gx[b][:] + 1e-6)) + shift[k],
     // mean from grn_part [samples, grn_np] (Epilogue::grn_part_out of the GEMM that produced A); a_rows_per_sample as above
     const float* grn_gx;       // [samples, K] or null

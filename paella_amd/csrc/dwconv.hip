@@ -25,12 +25,14 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 template <int NV, bool SKIP>
 __global__ __launch_bounds__(256) void dwconv_ln_block_kernel(const float* __restrict__ x, const float* __restrict__ skip,
                                                               const float* __restrict__ w, const float* __restrict__ bias,
-                                                              float* __restrict__ y, int H, int W, int C, float eps) {
+                                                              float* __restrict__ y, int H, int W, int C, float eps, FastDiv dW, FastDiv dH) {
     __shared__ float red[4];
     const int64_t pos = blockIdx.x;
     const int C4 = C >> 2;
-    const int xx = (int)(pos % W);
-    const int yy = (int)((pos / W) % H);
+    // (position -> (y, x) by multiply-high: a 64-bit division by a runtime value is ~100 instructions in front of this latency-bound kernel's first load)
+    const unsigned prow = fast_div((unsigned)blockIdx.x, dW);  // b * H + y
+    const int xx = (int)((unsigned)blockIdx.x - prow * (unsigned)W);
+    const int yy = (int)(prow - fast_div(prow, dH) * (unsigned)H);
     const int64_t img = pos - (int64_t)yy * W - xx;  // row index of (b, 0, 0)
     int c4s[NV];
     bool live[NV];
@@ -99,10 +101,11 @@ int launch_dwconv_ln(const float* x, const float* skip, const float* w, const fl
     if (total > 0x7fffffff) { paella_set_error("dwconv_ln: too many positions"); return PAELLA_ERR_ARG; }
     const int nv = (C / 4 + 255) / 256;
     const dim3 grid((unsigned)total), block(256);
+    const FastDiv dW = fast_div_of((unsigned)W), dH = fast_div_of((unsigned)H);
 #define DW_LAUNCH(NVv)                                                                                                   \
     do {                                                                                                                 \
-        if (skip) hipLaunchKernelGGL((dwconv_ln_block_kernel<NVv, true>), grid, block, 0, st, x, skip, w, bias, y, H, W, C, eps); \
-        else hipLaunchKernelGGL((dwconv_ln_block_kernel<NVv, false>), grid, block, 0, st, x, skip, w, bias, y, H, W, C, eps);     \
+        if (skip) hipLaunchKernelGGL((dwconv_ln_block_kernel<NVv, true>), grid, block, 0, st, x, skip, w, bias, y, H, W, C, eps, dW, dH); \
+        else hipLaunchKernelGGL((dwconv_ln_block_kernel<NVv, false>), grid, block, 0, st, x, skip, w, bias, y, H, W, C, eps, dW, dH);     \
     } while (0)
     if (nv <= 1) DW_LAUNCH(1);
     else if (nv <= 2) DW_LAUNCH(2);

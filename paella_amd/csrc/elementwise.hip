@@ -317,15 +317,18 @@ template <int P>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void embed_ln_unshuffle_kernel(const int64_t* __restrict__ tokens,
                                                                                  const float* __restrict__ table,
                                                                                  float* __restrict__ out, int B, int H,
-                                                                                 int W, int c_in, int num_labels, float eps) {
+                                                                                 int W, int c_in, int num_labels, float eps, FastDiv dWo, FastDiv dHo) {
     const int lane = threadIdx.x & 63;
     const int Ho = H / P, Wo = W / P;
     const int64_t opos = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
     const int64_t total = (int64_t)B * Ho * Wo;
     if (opos >= total) return;
-    const int ox = (int)(opos % Wo);
-    const int oy = (int)((opos / Wo) % Ho);
-    const int64_t b = opos / ((int64_t)Ho * Wo);
+    // (output position -> (b, oy, ox) by multiply-high; total < 2^31 is checked by the launcher: three 64-bit divisions by runtime values were ~500 instructions
+    // in front of the first token load)
+    const unsigned orow_i = fast_div((unsigned)opos, dWo);  // b * Ho + oy
+    const int ox = (int)((unsigned)opos - orow_i * (unsigned)Wo);
+    const int64_t b = fast_div(orow_i, dHo);
+    const int oy = (int)(orow_i - (unsigned)b * (unsigned)Ho);
     const int C4 = c_in >> 2;
     float* orow = out + opos * ((int64_t)c_in * P * P);
     // statistics per token (full row; the 8 MB table is L2/MALL resident), then the normalised
@@ -363,13 +366,15 @@ int launch_embed_ln_unshuffle(const int64_t* tokens, const float* table, float* 
     }
     const int64_t total = (int64_t)B * (H / patch) * (W / patch);
     if (total <= 0) return PAELLA_OK;
+    if (total > 0x7fffffff) { paella_set_error("embed: too many positions"); return PAELLA_ERR_ARG; }
     const unsigned blocks = (unsigned)((total + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+    const FastDiv dWo = fast_div_of((unsigned)(W / patch)), dHo = fast_div_of((unsigned)(H / patch));
     if (patch == 2)
         hipLaunchKernelGGL((embed_ln_unshuffle_kernel<2>), dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, st, tokens, table, out,
-                           B, H, W, c_in, num_labels, eps);
+                           B, H, W, c_in, num_labels, eps, dWo, dHo);
     else
         hipLaunchKernelGGL((embed_ln_unshuffle_kernel<1>), dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, st, tokens, table, out,
-                           B, H, W, c_in, num_labels, eps);
+                           B, H, W, c_in, num_labels, eps, dWo, dHo);
     LAUNCH_CHECK_RET();
     return PAELLA_OK;
 }
@@ -463,6 +468,14 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict_
         dst[r * ldd + c] = src[r * lds_ + c];
     }
 }
+// the common case (everything a multiple of 4 floats, fewer than 2^31 quads): 16-byte copies, row index by multiply-high
+__global__ __launch_bounds__(256) void copy_rows4_kernel(const float* __restrict__ src, int lds_, float* __restrict__ dst, int ldd, unsigned total4, int cols4, FastDiv dC) {
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total4; i += gridDim.x * 256u) {
+        const unsigned r = fast_div(i, dC);
+        const unsigned c = (i - r * (unsigned)cols4) * 4u;
+        st4(dst + (size_t)r * ldd + c, ld4(src + (size_t)r * lds_ + c));
+    }
+}
 // x = a*x + b*y over n floats (n % 4 == 0): classifier-free-guidance mix of the two halves ahead of the linear head
 __global__ __launch_bounds__(256) void axpby_kernel(float* __restrict__ x, const float* __restrict__ y, float a, float b, int64_t n4) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) st4(x + i * 4, ld4(x + i * 4) * a + ld4(y + i * 4) * b);
@@ -479,6 +492,14 @@ int launch_axpby(float* x, const float* y, float a, float b, int64_t n, hipStrea
 
 int launch_copy_rows(const float* src, int lds_, float* dst, int ldd, int64_t rows, int cols, hipStream_t st) {
     if (rows <= 0 || cols <= 0) return PAELLA_OK;
+    if (!((cols | lds_ | ldd) & 3) && !(((uintptr_t)src | (uintptr_t)dst) & 15) && rows * (cols / 4) < 0x7fffffff) {
+        const int64_t total4 = rows * (cols / 4);
+        int64_t blocks4 = (total4 + 255) / 256;
+        if (blocks4 > 4096) blocks4 = 4096;
+        hipLaunchKernelGGL(copy_rows4_kernel, dim3((unsigned)blocks4), dim3(256), 0, st, src, lds_, dst, ldd, (unsigned)total4, cols / 4, fast_div_of((unsigned)(cols / 4)));
+        LAUNCH_CHECK_RET();
+        return PAELLA_OK;
+    }
     int64_t blocks = (rows * cols + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, st, src, lds_, dst, ldd, rows, cols);

@@ -44,6 +44,8 @@ struct SkPlan {
     int tiles_m, tiles_n;  // tile grid
     int KT;                // K steps per tile
     unsigned U;            // tiles_m * tiles_n * KT work units
+    unsigned G;            // workgroups of the launch (== gridDim.x; carried here so that it arrives with the rest of the plan in ONE kernel-argument fetch)
+    FastDiv dKT, dTM, dQ, dQ1;  // divisions by KT, tiles_m, q, q + 1
     unsigned q, r;         // U = G*q + r: workgroup g owns [g*q + min(g, r), +q + (g < r)) -- 32-bit arithmetic only on the device
     int stagger;           // 256x128 tile: which waves run their non-MFMA phase late (0 none, 1 waves >= 4, 2 odd waves)
     int gm;                // tile rasterisation: groups of gm tile rows, m fastest inside a group, then n, then the next group.
@@ -56,8 +58,8 @@ struct SkPlan {
 template <bool GROUPED>
 __device__ __forceinline__ void sk_tile_coords(const SkPlan& p, int tile, int& tile_m, int& tile_n) {
     if (!GROUPED || p.gm >= p.tiles_m) {
-        tile_m = tile % p.tiles_m;
-        tile_n = tile / p.tiles_m;
+        tile_n = (int)fast_div((unsigned)tile, p.dTM);
+        tile_m = tile - tile_n * p.tiles_m;
     } else {
         const int width = p.gm * p.tiles_n;
         const int grp = tile / width, rem = tile - grp * width;
@@ -72,7 +74,7 @@ __device__ __forceinline__ void sk_tile_coords(const SkPlan& p, int tile, int& t
 __device__ __forceinline__ unsigned sk_start(const SkPlan& p, unsigned g) { return g * p.q + min(g, p.r); }
 __device__ __forceinline__ unsigned sk_owner(const SkPlan& p, unsigned x) {
     const unsigned big = p.r * (p.q + 1);  // units covered by the r workgroups that own q + 1 units
-    return x < big ? x / (p.q + 1) : p.r + (x - big) / p.q;
+    return x < big ? fast_div(x, p.dQ1) : p.r + fast_div(x - big, p.dQ);
 }
 
 // buffer_load_dwordx4 ... offen lds: 64 lanes x 16 bytes from (descriptor + per-lane offset + uniform offset) straight into LDS at
@@ -108,6 +110,7 @@ template <int WM, int WN, int TM, int TN, int PD, int APRO, bool TAIL = false, i
 // neither a ds_read latency nor a store phase ever sits in front of an idle matrix core; the GRN prologue is applied to the fragments from a side
 // stage that holds the scale rows of up to 16 consecutive samples.
 __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (WM * WN == 8 ? 1 : TM * TN == 1 ? (RING == 3 ? 5 : 4) : (TM * TN == 2 ? 4 : 3))
+                                           : (TAIL && DMA) ? 4  // fused head + tail on the 64x64 direct-to-LDS tile: four independent workgroups per CU
                                            : (TAIL && WM * WN == 8 && TM * TN == 4) ? 4  // fused head + tail on 128x64 tiles: TWO+ workgroups per CU, one's Philox / log epilogue overlaps another's main loop
                                            : (WM == 2 && WN == 2 && TM * TN == 1 && PD == 2 && BK == 32 && APRO != 1) ? 5
                                            : (DMA && WM * WN == 4 && TM * TN == 16) ? 2  // 128x128 on 4 waves, direct-to-LDS: two independent workgroups per CU (64 KiB of LDS each)
@@ -127,7 +130,7 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (WM * WN == 8 ? 1 : TM * T
     // lane-linear; the XOR swizzle of the 16-byte slots is applied to the SOURCE address instead (lane l of a row fetches chunk
     // (l % 8) ^ (row % 8)).  Needs K % BK == 0 (no activation-side K-tail mask) -- the host picks the register-staged twin otherwise.
     constexpr bool DMA_W = DMA || RING > 0, DMA_A = (DMA && (APRO == 0 || APRO == 2)) || RING > 0;  // (the LayerNorm is folded into the epilogue: the operand stays raw)
-    static_assert(!DMA || (PD == 1 && BK == 32 && !TAIL && (BM * SL) % NT == 0 && (BN * SL) % NT == 0), "DMA variant: 1-deep, K step 32, whole passes");
+    static_assert(!DMA || (PD == 1 && BK == 32 && (BM * SL) % NT == 0 && (BN * SL) % NT == 0), "DMA variant: 1-deep, K step 32, whole passes");
     static_assert(RING == 0 || (RING >= 3 && RING <= 4 && !DMA && PD == 1 && BK == 32 && !TAIL && APRO != 3 && (NW == 4 || (TM == 4 && TN == 4 && RING == 3)) && (BM * SL) % NT == 0 && (BN * SL) % NT == 0),
                   "ring variant: 3 or 4 LDS stages, 4 waves (or 8 waves of 64x64 wave tiles), K step 32, whole passes, no implicit convolution");
     static_assert(APRO != 4 || RING > 0, "the GRN-from-raw-statistics prologue exists on ring tiles only");
@@ -148,16 +151,18 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (WM * WN == 8 ? 1 : TM * T
     __shared__ __attribute__((aligned(16))) float smem[FLAG_OFF + 16 + TAIL_FLOATS + GRN_SCR];
 
     // ---- this workgroup's unit range ----
-    const unsigned G = gridDim.x;
+    // (everything up to the first operand fetch is latency on every launch: no branch -- the kernel-argument loads of the whole prologue then issue as one
+    // batch instead of one round trip per basic block -- and no division by a runtime value)
+    const unsigned G = p.G;
     unsigned gid = blockIdx.x;
     {
         const unsigned q = G >> 3, r = G & 7;
         const unsigned xcd = gid & 7, idx = gid >> 3;
-        gid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        gid = xcd * q + min(xcd, r) + idx;  // XCD x owns the contiguous logical ids [x*q + min(x, r), ...): q + 1 of them when x < r
     }
     const unsigned u0 = sk_start(p, gid);
     const int n = (int)(p.q + (gid < p.r ? 1u : 0u));
-    if (n <= 0) return;  // host keeps G <= U, so every workgroup owns at least one unit
+    __builtin_assume(n > 0);  // host keeps G <= U, so every workgroup owns at least one unit
 #ifdef PAELLA_GEMM_CLOCK_PROBE  // tools/probes/gemm_clock_probe.py builds its own library with this: shader clock the launch really ran at
     const unsigned long long cp_t0 = __builtin_readcyclecounter(), cp_w0 = wall_clock64();
 #endif
@@ -196,7 +201,7 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (WM * WN == 8 ? 1 : TM * T
     // Operands are read through buffer descriptors: per-thread 32-bit byte offsets (recomputed only when the cursor enters a new
     // tile) + ONE uniform K offset in an SGPR per unit -> no vector address arithmetic in the unit loop.  Reads past the end of a
     // buffer return 0 (hardware range check), so only the M / N clamps remain; the K tail is masked when the tile is staged.
-    int ltile = (int)(u0 / (unsigned)KT);
+    int ltile = (int)fast_div(u0, p.dKT);
     int lkt = (int)(u0 - (unsigned)ltile * (unsigned)KT);
     auto rsrc_of = [](const float* ptr, size_t bytes) {
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ptr), 0, (int)(bytes > 0xffffffffull ? 0xffffffffull : bytes), 0x00020000);
@@ -231,8 +236,8 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (WM * WN == 8 ? 1 : TM * T
         const size_t w_base = (size_t)n0 * g.ldw * sizeof(float);
         rsrcW = rsrc_of(reinterpret_cast<const float*>(reinterpret_cast<const char*>(g.W) + w_base), w_bytes - w_base);
         if (APRO == 1 || APRO == 4) {
-            smp0 = m0 / g.a_rows_per_sample;
-            const size_t s_bytes = (size_t)((g.M - 1) / g.a_rows_per_sample + 1) * g.K * sizeof(float), s_base = (size_t)smp0 * g.K * sizeof(float);
+            smp0 = (int)fast_div((unsigned)m0, g.a_rps_div);
+            const size_t s_bytes = (size_t)(fast_div((unsigned)(g.M - 1), g.a_rps_div) + 1) * g.K * sizeof(float), s_base = (size_t)smp0 * g.K * sizeof(float);
             rsrcS = rsrc_of((APRO == 4 ? g.grn_gx : g.a_scale) + (size_t)smp0 * g.K, s_bytes - s_base);
         }
 #pragma unroll
@@ -248,10 +253,10 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (WM * WN == 8 ? 1 : TM * T
             } else {
                 aoff[i] = ((unsigned)(gmc - m0) * (unsigned)g.lda + (unsigned)((DMA_A ? (ldc4 ^ (ldrow & (SL - 1))) : ldc4) * 4)) * 4u;
             }
-            if (APRO == 1 && RING == 0) soff[i] = ((unsigned)(gmc / g.a_rows_per_sample - smp0) * (unsigned)g.K + (unsigned)(ldc4 * 4)) * 4u;
+            if (APRO == 1 && RING == 0) soff[i] = ((unsigned)((int)fast_div((unsigned)gmc, g.a_rps_div) - smp0) * (unsigned)g.K + (unsigned)(ldc4 * 4)) * 4u;
         }
         if (GRN_SIDE) {
-            const int last = (g.M - 1) / g.a_rows_per_sample - smp0;  // clamp: rows past the last sample re-read it (never used)
+            const int last = (int)fast_div((unsigned)(g.M - 1), g.a_rps_div) - smp0;  // clamp: rows past the last sample re-read it (never used)
             aux_s_off = ((unsigned)min(lane_k >> 3, last) * (unsigned)g.K + (unsigned)((lane_k & 7) * 4)) * 4u;
             if (BIG) aux_s_off2 = ((unsigned)min(8 + (lane_k >> 3), last) * (unsigned)g.K + (unsigned)((lane_k & 7) * 4)) * 4u;
         }
@@ -780,9 +785,9 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (WM * WN == 8 ? 1 : TM * T
             if (!GRN_SIDE) return;
             int tile_m, tile_n;
             sk_tile_coords<(BM >= 64)>(p, tile, tile_m, tile_n);
-            const int m0 = tile_m * BM, smp0 = m0 / g.a_rows_per_sample;
+            const int m0 = tile_m * BM, smp0 = (int)fast_div((unsigned)m0, g.a_rps_div);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) sidx[i] = min(m0 + (wm * TM + i) * 16 + r16, g.M - 1) / g.a_rows_per_sample - smp0;
+            for (int i = 0; i < TM; ++i) sidx[i] = (int)fast_div((unsigned)min(m0 + (wm * TM + i) * 16 + r16, g.M - 1), g.a_rps_div) - smp0;
             if (APRO == 4 && tile_m != rinv_tile_m) {
                 // mean_k gx of the fragment rows' samples from the producer's per-(column tile, wave column) partial sums: the host guarantees
                 // a_rows_per_sample % 16 == 0, so the 16 rows of a fragment belong to ONE sample and the whole wave reduces its grn_np numbers
@@ -888,7 +893,7 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (WM * WN == 8 ? 1 : TM * T
         for (int j = 0; j < RING - 1; ++j) fetch_ring(j);
         ln_row_stats();  // while the first units are in flight
         int cs = 0, ls = RING - 1;
-        int ctile = (int)(u0 / (unsigned)KT);
+        int ctile = (int)fast_div(u0, p.dKT);
         int ckt = (int)(u0 - (unsigned)ctile * (unsigned)KT);
         bool first_seg = true;
         if constexpr (BIG) {
@@ -1033,9 +1038,9 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (WM * WN == 8 ? 1 : TM * T
     ln_row_stats();  // while the first units are in flight
     store_unit(R[0], 0);
     __syncthreads();
-    if constexpr (PIPE) read_group(std::integral_constant<int, 0>{}, 0, (int)(u0 % (unsigned)KT));
+    if constexpr (PIPE) read_group(std::integral_constant<int, 0>{}, 0, (int)(u0 - fast_div(u0, p.dKT) * (unsigned)KT));
 
-    int ctile = (int)(u0 / (unsigned)KT);
+    int ctile = (int)fast_div(u0, p.dKT);
     int ckt = (int)(u0 - (unsigned)ctile * (unsigned)KT);
     bool first_seg = true;
     int slot = 0;
@@ -1439,6 +1444,8 @@ extern "C" int paella_test_ln_fold_ratio(float ratio) { g_ln_fold_ratio = ratio;
 int launch_gemm_cfg(const GemmArgs& g_in, int cfg, int splitk, void* ws, size_t ws_bytes, hipStream_t st) {
     GemmArgs g = g_in;
     g.ln_fold_ratio = g_ln_fold_ratio.load(std::memory_order_relaxed);
+    g.a_rps_div = fast_div_of((unsigned)(g.a_rows_per_sample > 0 ? g.a_rows_per_sample : 1));
+    g.ep.rps_div = fast_div_of((unsigned)(g.ep.rows_per_sample > 0 ? g.ep.rows_per_sample : 1));
     return prof_bracket(g, st, true, [&]() { return launch_gemm_cfg_impl(g, cfg, splitk, ws, ws_bytes, st); });
 }
 
@@ -1582,6 +1589,8 @@ static int launch_gemm_cfg_impl(const GemmArgs& g_in, int cfg, int splitk, void*
     }
     p.q = p.U / G;
     p.r = p.U % G;
+    p.G = G;
+    p.dKT = fast_div_of((unsigned)p.KT); p.dTM = fast_div_of((unsigned)p.tiles_m); p.dQ = fast_div_of(p.q); p.dQ1 = fast_div_of(p.q + 1);
     // grouped rasterisation for launches with many tile rows and columns (test hook: paella_test_gemm_raster)
     // (32-row tiles and skinny problems keep the plain order: their traffic is the weight panel, which m-fastest tiles share best --
     // measured +2 % per image at batch 1 with groups there)
@@ -1645,9 +1654,9 @@ static int launch_gemm_cfg_impl(const GemmArgs& g_in, int cfg, int splitk, void*
 // ---------------------------------------------------------------------------
 // tile of the fused head + tail: 9 = 128x128 (one workgroup per CU: the Philox / log epilogue serialises behind the main loop), 14 = 128x64 8 waves
 // (two or more workgroups per CU overlap epilogue and main loop; twice the per-row partials).  A/B through the test hook only.
-static std::atomic<int> g_tail_tile{14};
+static std::atomic<int> g_tail_tile{18};
 extern "C" int paella_test_gemm_tail_tile(int cfg) {
-    if (cfg != 9 && cfg != 14) { paella_set_error("fused-tail tile must be 9 (128x128) or 14 (128x64)"); return PAELLA_ERR_ARG; }
+    if (cfg != 9 && cfg != 14 && cfg != 18) { paella_set_error("fused-tail tile must be 9 (128x128), 14 (128x64) or 18 (64x64, direct-to-LDS)"); return PAELLA_ERR_ARG; }
     g_tail_tile = cfg;
     return PAELLA_OK;
 }
@@ -1658,7 +1667,10 @@ int gemm_tail_tiles_n(int M, int N) {
     return (N + BN - 1) / BN;
 }
 static int launch_gemm_tail_impl(const GemmArgs& g, hipStream_t st);
-int launch_gemm_tail(const GemmArgs& g, hipStream_t st) {
+int launch_gemm_tail(const GemmArgs& g_in, hipStream_t st) {
+    GemmArgs g = g_in;
+    g.a_rps_div = fast_div_of(1u);
+    g.ep.rps_div = fast_div_of((unsigned)(g.ep.rows_per_sample > 0 ? g.ep.rows_per_sample : 1));
     return prof_bracket(g, st, false, [&]() { return launch_gemm_tail_impl(g, st); });  // (no logits are stored: M*N bytes not counted)
 }
 static int launch_gemm_tail_impl(const GemmArgs& g, hipStream_t st) {
@@ -1684,12 +1696,15 @@ static int launch_gemm_tail_impl(const GemmArgs& g, hipStream_t st) {
     p.stagger = 0;
     p.q = (unsigned)(p.U / G);
     p.r = 0;
+    p.G = (unsigned)G;
+    p.dKT = fast_div_of((unsigned)p.KT); p.dTM = fast_div_of((unsigned)p.tiles_m); p.dQ = fast_div_of(p.q); p.dQ1 = fast_div_of(p.q + 1);
     // grouped rasterisation as in the unfused launches: with K = c_out = 256 a tile moves 196 KB of operands for 4.2 MFLOP, and in plain m-fastest order no two
     // tiles that run together share an activation panel -- the whole activation matrix crosses the fabric once per column tile (34 GB per launch at configs[2])
     const int raster_gm = g_gemm_raster_gm;
     p.gm = (raster_gm > 0 && BM >= 64 && p.tiles_m >= 4 * raster_gm && p.tiles_n >= 4) ? raster_gm : p.tiles_m;
     if (cfg == 9) hipLaunchKernelGGL((gemm_nt_kernel<4, 2, 2, 4, 1, 0, true>), dim3((unsigned)G), dim3(512), 0, st, g, p, (float*)nullptr, (unsigned*)nullptr, 0u);
     else if (cfg == 14) hipLaunchKernelGGL((gemm_nt_kernel<4, 2, 2, 2, 2, 0, true>), dim3((unsigned)G), dim3(512), 0, st, g, p, (float*)nullptr, (unsigned*)nullptr, 0u);
+    else if (cfg == 18 && g.K % 32 == 0 && g_gemm_dma) hipLaunchKernelGGL((gemm_nt_kernel<2, 2, 2, 2, 1, 0, true, 32, true>), dim3((unsigned)G), dim3(256), 0, st, g, p, (float*)nullptr, (unsigned*)nullptr, 0u);
     else hipLaunchKernelGGL((gemm_nt_kernel<2, 2, 2, 2, 2, 0, true>), dim3((unsigned)G), dim3(256), 0, st, g, p, (float*)nullptr, (unsigned*)nullptr, 0u);
     LAUNCH_CHECK_RET();
     return PAELLA_OK;

@@ -16,7 +16,7 @@ __device__ __forceinline__ f32x4 epilogue_apply(const Epilogue& ep, int N, int m
     if (ep.alpha != 1.0f) v *= ep.alpha;
     if (ep.residual) v += *reinterpret_cast<const f32x4*>(ep.residual + (size_t)m * ep.ldr + n);
     if (ep.ts) {
-        const float* t = ep.ts + (size_t)(m / ep.rows_per_sample) * ep.ts_stride;
+        const float* t = ep.ts + (size_t)fast_div((unsigned)m, ep.rps_div) * ep.ts_stride;
         f32x4 a = *reinterpret_cast<const f32x4*>(t + n);
         f32x4 b = *reinterpret_cast<const f32x4*>(t + N + n);
         v = v * (1.0f + a) + b;

@@ -5,6 +5,7 @@
 // gemm.hip / elementwise.hip / attention.hip, activations stay NHWC in a caller-owned workspace arena, and
 // nothing synchronises the host.  Weights are repacked once at load (paella_unet_load_tensor).
 #include "internal.h"
+#include "test_hooks.h"
 #include "../../include/paella_hip.h"
 
 #include <math.h>
@@ -431,9 +432,7 @@ extern "C" int paella_unet_finalize(paella_unet* m, void* stream) {
         RET_IF(devbuf_alloc(m->kv_b, (size_t)total));
         DevBuf wkv_t;
         RET_IF(devbuf_alloc(wkv_t, (size_t)cc * m->c_max));
-        void* ws = nullptr;
-        HIP_CHECK_RET(hipMalloc(&ws, kGemmTicketBytes + ((size_t)64 << 20)));
-        int rc = paella_workspace_init(ws, kGemmTicketBytes, st);
+        int rc = PAELLA_OK;  // (both launches below run one whole tile per workgroup: no split-K workspace, nothing to allocate per reload -- ADVICE r03)
         auto compose = [&](const Block& b) -> int {
             if (b.type != BT_ATTN) return PAELLA_OK;
             const int ch = b.c;
@@ -444,17 +443,16 @@ extern "C" int paella_unet_finalize(paella_unet* m, void* stream) {
             RET_IF(launch_permute(T(m, b.prefix + ".kv_mapper.1.weight"), wkv_t.p, shp, perm, 2, st));  // [ch, cc] -> [cc, ch]
             // kv_w rows [col, col + 2ch): C[2ch, cc] = Win[c:3c] [2ch, ch] . (Wkv^T [cc, ch])^T
             GemmArgs g = gemm_args(win, ch, wkv_t.p, ch, m->kv_w.p + (size_t)m->kv_col[b.attn_index] * cc, cc, 2 * ch, cc, ch);
-            RET_IF(launch_gemm_cfg(g, 18, 1, ws, kGemmTicketBytes + ((size_t)64 << 20), st));  // (explicit fp32 tile: never the bf16 fast mode)
+            RET_IF(launch_gemm_cfg(g, 18, 1, nullptr, 0, st));  // (explicit fp32 tile: never the bf16 fast mode)
             // kv_b: C[1, 2ch] = bkv [1, ch] . Win[c:3c]^T + bin[c:3c]
             GemmArgs gb = gemm_args(T(m, b.prefix + ".kv_mapper.1.bias"), ch, win, ch, m->kv_b.p + m->kv_col[b.attn_index], 2 * ch, 1, 2 * ch, ch);
             gb.ep.bias = bin;
-            RET_IF(launch_gemm_cfg(gb, 5, 1, ws, kGemmTicketBytes + ((size_t)64 << 20), st));
+            RET_IF(launch_gemm_cfg(gb, 5, 1, nullptr, 0, st));
             return PAELLA_OK;
         };
         if (rc == PAELLA_OK) for (const Block& b : m->down) { rc = compose(b); if (rc != PAELLA_OK) break; }
         if (rc == PAELLA_OK) for (const Block& b : m->up) { rc = compose(b); if (rc != PAELLA_OK) break; }
         if (hipStreamSynchronize(st) != hipSuccess && rc == PAELLA_OK) { paella_set_error("finalize: stream error while composing the conditioning projections"); rc = PAELLA_ERR_HIP; }
-        (void)hipFree(ws);
         if (wkv_t.p) (void)hipFree(wkv_t.p);
         if (rc != PAELLA_OK) return rc;
         RET_IF(gemm_register_weight(m->kv_w.p, m->kv_w.n, st));

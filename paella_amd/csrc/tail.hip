@@ -12,6 +12,7 @@
 // Noise comes either from caller-provided tensors (parity mode: bit-identical draws to torch given the
 // same q / u) or from an in-kernel Philox4x32-10 stream keyed by (seed, offset).
 #include "common.h"
+#include "test_hooks.h"
 #include "philox.h"
 #include <math.h>
 

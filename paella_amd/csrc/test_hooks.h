@@ -27,7 +27,7 @@ int paella_test_mlp_grn_fused(const float* h, const float* W1, const float* b1, 
 int paella_test_gemm_dma(int on);
 /* the LDS-DMA ring tile (config id 30..35) the launch heuristic uses for the skinny batch-1 shapes; 0 = the register-staged / 1-deep kernels (A/B) */
 int paella_test_gemm_ring(int cfg);
-/* tile of the fused head GEMM + sampling tail: 9 = 128x128 (default), 14 = 128x64 with several workgroups per CU (A/B) */
+/* tile of the fused head GEMM + sampling tail: 9 = 128x128, 14 = 128x64 on 8 waves (several workgroups per CU), 18 = 64x64 direct-to-LDS (four workgroups per CU) */
 int paella_test_gemm_tail_tile(int cfg);
 /* tile rows per rasterisation group of the GEMM (default 8); 0 = plain m-fastest tile order (A/B) */
 int paella_test_gemm_raster(int gm);

@@ -59,11 +59,13 @@ class _InferenceOnly(torch.autograd.Function):
     and has no backward kernels, so `loss.backward()` through an eval-mode forward raises here and names the fix."""
 
     @staticmethod
-    def forward(ctx, out, anchor):
-        return out.view_as(out)
+    def forward(ctx, anchor, run):
+        # the engine runs INSIDE the Function, so the result is a fresh tensor of this node (not a view of an input): in-place edits of the
+        # logits work as on the reference's output, and nothing is copied (ADVICE r03)
+        return run()
 
     @staticmethod
-    def backward(ctx, grad):
+    def backward(ctx, grad):  # (gradients for: anchor, run)
         raise RuntimeError("paella_amd.Paella was evaluated in eval mode (the hand-written HIP inference engine, which has no backward); "
                            "call model.train() before the forward for the differentiable path (paella_amd/training.py)")
 
@@ -431,14 +433,17 @@ class Paella(nn.Module):
         if x_cat is not None:
             x = torch.cat([x, x_cat], dim=1)
         cond = self.prepare_cond(byt5, clip, clip_image)
-        out = self.forward_prepared(x, r, cond, attn_weights=kwargs.get("attn_weights"))
+        run = lambda: self.forward_prepared(x, r, cond, attn_weights=kwargs.get("attn_weights"))
         if torch.is_grad_enabled():
             # like the reference module's, an eval-mode result computed with gradients enabled is attached to the parameters -- but
             # backpropagating through it fails with a message that names model.train() instead of 'does not require grad'
-            anchor = next((p for p in self.parameters() if p.requires_grad), None)
+            anchor = getattr(self, "_grad_anchor", None)
+            if anchor is None or not anchor.requires_grad:
+                anchor = next((p for p in self.parameters() if p.requires_grad), None)
+                object.__setattr__(self, "_grad_anchor", anchor)  # (plain attribute: not a registered parameter)
             if anchor is not None:
-                out = _InferenceOnly.apply(out, anchor)
-        return out
+                return _InferenceOnly.apply(anchor, run)
+        return run()
 
     # ------------------------------------------------------------------ add_noise / loss weight
     def add_noise(self, x, t, mask=None, random_x=None):

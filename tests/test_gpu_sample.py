@@ -464,8 +464,9 @@ def test_graph_sampler_shard_equals_unsharded(tiny):
         gs(seed=1, shard=(3, 4))
 
 
+@pytest.mark.parametrize("tail_tile", [14, 18, 9])
 @pytest.mark.parametrize("cfg_name,B,grid", [("UNET_TINY", 3, 16), ("UNET_MID", 2, 16), ("UNET_570M", 1, 32)])
-def test_fused_head_tail_is_bit_identical_to_the_two_kernel_path(built_lib, cfg_name, B, grid):
+def test_fused_head_tail_is_bit_identical_to_the_two_kernel_path(built_lib, cfg_name, B, grid, tail_tile):
     """out_mapper fused with the sampling tail (no logits tensor; SURVEY section 7 step 3, reference src/utils.py:44-50): same
     tokens, bit for bit, as head GEMM -> logits -> tail kernel on the same Philox seed -- closed loop (every later step would
     amplify a single differing token), with guidance (mix folded through the head), without guidance, and with an argmax step."""
@@ -475,6 +476,15 @@ def test_fused_head_tail_is_bit_identical_to_the_two_kernel_path(built_lib, cfg_
     m = m.to(DEV)
     cs, us = to_dev(cond_for(cfg, B, 3, 0, 1), DEV), to_dev(cond_for(cfg, B, 3, 0, 2), DEV)
     kw = dict(steps=3, renoise_steps=2, device=DEV, noise="philox", seed=4242)
+    default_tile = 18  # paella_amd/csrc/gemm.hip g_tail_tile (only heads of >= 256 tiles of 128x128 use it: the 570M case here)
+    built_lib.paella_test_gemm_tail_tile(tail_tile)
+    try:
+        _fused_vs_unfused(m, cfg, cfg_name, cs, us, B, grid, kw)
+    finally:
+        built_lib.paella_test_gemm_tail_tile(default_tile)
+
+
+def _fused_vs_unfused(m, cfg, cfg_name, cs, us, B, grid, kw):
     for extra in (dict(unconditional_inputs=us, cfg=8.0, temperature=(1.0, 0.3)),
                   dict(unconditional_inputs=None, cfg=None, temperature=(0.9, 0.4)),
                   dict(unconditional_inputs=None, cfg=None, temperature=(0.5, 0.0))):   # last step T = 0 -> argmax mode

@@ -101,5 +101,9 @@ def test_eval_mode_forward_refuses_autograd(built_lib):
         assert out.requires_grad  # like the reference module's eval-mode output
         with pytest.raises(RuntimeError, match=r"model\.train\(\)"):
             out.sum().backward()
+        out2 = m(x, torch.zeros(1, device=DEV), **c)
+        ref = out2.detach().clone()
+        out2.mul_(2.0)  # in-place edits of the logits work as on the reference's output: the result is not a view created inside a custom Function
+        assert torch.equal(out2.detach(), ref * 2.0)
     with torch.no_grad():
         assert not m(x, torch.zeros(1, device=DEV), **c).requires_grad

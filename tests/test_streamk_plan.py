@@ -128,3 +128,35 @@ def test_grouped_rasterisation_is_a_bijection_with_block_locality(tiles_m, tiles
             if win[0][0] // gm != win[-1][0] // gm:
                 continue  # window straddles two row groups
             assert len({m for m, _ in win}) <= gm and len({n for _, n in win}) <= 5
+
+
+def _fast_div_of(d):
+    """Mirror of paella_amd/csrc/gemm.hip fast_div_of / fast_div: n // d for n < 2^31 as one multiply-high and one shift."""
+    if d <= 1:
+        return 0, 0, 0xffffffff
+    l = 0
+    while (1 << l) < d:
+        l += 1
+    mul = ((1 << (31 + l)) + d - 1) // d
+    assert mul < (1 << 32)
+    return mul, l - 1, 0
+
+
+def _fast_div(n, f):
+    mul, shr, pas = f
+    return (((n * mul) >> 32) + (n & pas)) >> shr
+
+
+def test_fast_div_is_exact_below_2_pow_31():
+    """The GEMM kernel divides unit / tile indices (< 2^31, enforced by the launcher) by launch constants with a precomputed multiplier: exact for every
+    divisor class (1, powers of two, 2^k +- 1, large, random) at the range's edges and at random points."""
+    import random
+    rng = random.Random(5)
+    ds = [1, 2, 3, 5, 7, 10, 40, 41, 160, 641, 1280, 5120, 65535, 65536, 65537, (1 << 20) - 1, (1 << 30) + 1, (1 << 31) - 1] + [rng.randrange(1, 1 << 31) for _ in range(300)]
+    for d in ds:
+        f = _fast_div_of(d)
+        ns = [0, 1, d - 1, d, d + 1, 2 * d - 1, 2 * d, (1 << 31) - 1, (1 << 31) - d, ((1 << 31) - 1) // d * d, ((1 << 31) - 1) // d * d - 1]
+        ns += [rng.randrange(0, 1 << 31) for _ in range(200)]
+        for n in ns:
+            if 0 <= n < (1 << 31):
+                assert _fast_div(n, f) == n // d, (n, d)

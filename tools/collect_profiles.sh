@@ -3,7 +3,7 @@
 # Output: gpurun_out/<tag>_profiles/ -- kernel-trace summaries (batch 1, batch 32, BASELINE configs[2]), the HBM traffic files
 # bench.py reads (tools/pmc_traffic.py; stamped with the kernel-source hash), matrix-core busy counters.  Counters are collected
 # in passes of their own with --kernel-trace only (MI355X_MICROARCH.md, HBM / rocprofv3 section).
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/${TAG}_profiles
 mkdir -p $O
@@ -56,4 +56,12 @@ python tools/gemm_by_shape.py --batch 64 --grid 64 --sample-steps 2 2>&1 | grep 
 # the parity report: every oracle / reference comparison with its near-tie counts printed (-s)
 { echo "# python -m pytest tests -m gpu -q -s -k 'parity or vs_oracle or vs_reference or closed_loop or benchmarked or geometry or train_step or prompts_to_image or graph_sampler or reproduces or grn_finished'   (MI355X)"
   python -m pytest tests -m gpu -q -s -p no:cacheprovider -k "parity or vs_oracle or vs_reference or closed_loop or benchmarked or geometry or train_step or prompts_to_image or graph_sampler or reproduces or grn_finished" 2>&1 | grep -v "amdgpu.ids" | grep -v "^\s*$"; } > $O/${TAG}_parity_report.txt
+# round 4: the LayerNorm-fold error curve (threshold hook at inf / 0 / default), the RCCL path at the box's world size
+{ echo "# python -m pytest tests/test_gpu_ops.py -q -s -k layernorm_fold   (MI355X): max |out - fp64| of a LayerNorm-consuming GEMM, K = 1280, outputs of unit scale, per |row mean| / std"
+  python -m pytest tests/test_gpu_ops.py -q -s -p no:cacheprovider -k "layernorm_fold" 2>&1 | grep "cfg\|passed\|failed" | sed 's/^[.F]*//'; } > $O/${TAG}_ln_fold_error_curve.txt
+{ echo "# python -m pytest tests/test_gpu_dist.py -q -s   (MI355X, world size = GPUs of the box): torch.distributed over nccl (= RCCL) with a live process group"
+  python -m pytest tests/test_gpu_dist.py -q -s -p no:cacheprovider 2>&1 | grep "^[.F]*{\|passed\|failed" | sed 's/^[.F]*//'; } > $O/${TAG}_rccl_world1.txt
+# the headline line with in-date traffic: the traffic files of THIS run go where bench.py looks for them
+cp $O/${TAG}_pmc_traffic_*.json $R/profiles/ 2>/dev/null
+python bench.py 2> $O/log_bench_line.txt | tail -1 > $O/${TAG}_bench_line.json
 ls -la $O
