@@ -351,7 +351,12 @@ class Paella(nn.Module):
 
     # ------------------------------------------------------------------ forward
     def forward_prepared(self, x, r, cond, attn_weights=None, out=None, cfg_mix=None, ws=None):
-        """One denoising evaluation against a `CondCache`. x int64 [Bx,H,W]; r fp32 [Bx].
+        """One denoising evaluation against a `CondCache` (see `_forward_prepared_raw`): logits with the reference's shape [B, num_labels, H, W], a channels-last
+        view of the position-major buffer the kernels write."""
+        return self._forward_prepared_raw(x, r, cond, attn_weights=attn_weights, out=out, cfg_mix=cfg_mix, ws=ws).permute(0, 3, 1, 2)
+
+    def _forward_prepared_raw(self, x, r, cond, attn_weights=None, out=None, cfg_mix=None, ws=None):
+        """One denoising evaluation against a `CondCache`, position-major result [B, H, W, num_labels].  x int64 [Bx,H,W]; r fp32 [Bx].
         Normally Bx == cond.B.  With Bx < cond.B (cond.B a multiple of Bx) the rows b, b + Bx, ... of the conditioning
         share the tokens and timestep of row b -- classifier-free guidance batches the conditional and unconditional pass
         that way -- and the conditioning-independent prefix of the network is computed once for the Bx distinct rows.
@@ -388,7 +393,7 @@ class Paella(nn.Module):
             _lib.check(lib.paella_unet_forward_shared(h, _lib.ptr(x), _lib.ptr(r), _lib.ptr(cond.buf), B, nu, mix[0], mix[1], H, W, cond.S, _lib.ptr(aw),
                                                       0 if aw is None else aw.numel(), _lib.ptr(out), _lib.ptr(ws), ws.numel(),
                                                       _lib.stream_ptr(dev)))
-        return out.permute(0, 3, 1, 2)
+        return out
 
     def forward_sample(self, x, r, cond, out, *, temperature, argmax=False, seed=0, seed_dev=None, offset=0, row_offset=0,
                        row_offset_dev=None, init_noise=None, t_next=0.0, cfg_mix=None, attn_weights=None, ws=None):
@@ -433,7 +438,10 @@ class Paella(nn.Module):
         if x_cat is not None:
             x = torch.cat([x, x_cat], dim=1)
         cond = self.prepare_cond(byt5, clip, clip_image)
-        run = lambda: self.forward_prepared(x, r, cond, attn_weights=kwargs.get("attn_weights"))
+        # (the engine writes position-major [B,H,W,L]; the reference's [B,L,H,W] shape is a permuted view of it -- the Function below returns the BASE tensor and
+        # the permute happens outside, as an ordinary differentiable view)
+        run_base = lambda: self._forward_prepared_raw(x, r, cond, attn_weights=kwargs.get("attn_weights"))
+        run = lambda: run_base().permute(0, 3, 1, 2)
         if torch.is_grad_enabled():
             # like the reference module's, an eval-mode result computed with gradients enabled is attached to the parameters -- but
             # backpropagating through it fails with a message that names model.train() instead of 'does not require grad'
@@ -442,7 +450,7 @@ class Paella(nn.Module):
                 anchor = next((p for p in self.parameters() if p.requires_grad), None)
                 object.__setattr__(self, "_grad_anchor", anchor)  # (plain attribute: not a registered parameter)
             if anchor is not None:
-                return _InferenceOnly.apply(anchor, run)
+                return _InferenceOnly.apply(anchor, run_base).permute(0, 3, 1, 2)
         return run()
 
     # ------------------------------------------------------------------ add_noise / loss weight
