@@ -66,3 +66,25 @@ def test_stale_library_is_refused(built_lib, monkeypatch):
     monkeypatch.setattr(_stamp, "source_stamp", lambda: "0" * 32)
     with pytest.raises(_lib.PaellaHipError, match="built from other sources"):
         _lib.load()
+
+
+def test_test_hooks_header_binding_and_library_agree(built_lib):
+    """paella_amd/csrc/test_hooks.h (tools / tests only, not the public ABI) is included by the translation units that define the hooks, so the compiler checks the
+    prototypes; here: the header, the ctypes table and the exported symbols name the same set, and none of them leaks into the public header."""
+    src = open(os.path.join(ROOT, "paella_amd", "csrc", "test_hooks.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(paella_[a-z0-9_]+)\s*\(", src)))
+    from paella_amd import _lib
+    assert declared == sorted(_lib.TEST_HOOKS), (set(declared) ^ set(_lib.TEST_HOOKS))
+    raw = ctypes.CDLL(os.path.join(ROOT, "paella_amd", "csrc", "libpaella_hip.so"))
+    for n in declared:
+        assert hasattr(raw, n), "libpaella_hip.so does not export " + n
+    assert not set(declared) & set(header_functions())
+
+
+def test_library_reads_no_environment_variables():
+    """A/B switches are test hooks; a deployment's kernels must not depend on the environment (three getenv knobs lived in gemm.hip)."""
+    csrc = os.path.join(ROOT, "paella_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".h")):
+            assert "getenv" not in open(os.path.join(csrc, f)).read(), f
