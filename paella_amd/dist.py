@@ -136,7 +136,7 @@ def broadcast_conditioning(input_sets, src=0, device=None, group=None, layout=No
                 from .sampling import fresh_seed
                 seed = fresh_seed()
             flat = torch.cat([flat, _pack_seed(seed, flat.device)])
-        flat = torch.cat([flat, torch.tensor([0.0 if bad else 1.0], dtype=torch.float32, device=flat.device)])
+        flat = torch.cat([flat, torch.full((1,), 0.0 if bad else 1.0, dtype=torch.float32, device=flat.device)])  # (a fill kernel, not a host-to-device copy)
     if layout is None:
         dist.broadcast_object_list(meta, src=src, group=group)
         descs, numel = meta[0]
