@@ -206,7 +206,7 @@ def gemm_roofline(lib, run_once, device, model, batch, grid, sample_steps, gemm,
     if algo is not None and ms.value > 0:
         ach = algo * batch * 1e9 / (ms.value * 1e-3) / 1e12
     return {"bound": "mfma", "kernel": ("gemm_nt_kernel (fp32 v_mfma_f32_16x16x4_f32, all tile configs, in-launch partial-tile combine included)" if gemm == "fp32"
-                                        else "gemm_bf16_kernel (v_mfma_f32_16x16x32_bf16) + fp32 gemm_nt_kernel for the few GEMMs without a bf16 path"),
+                                        else "gemm_nt_kernel, bf16-operand instantiations (v_mfma_f32_16x16x32_bf16, fp32 accumulate) + the fp32 instantiations for the GEMMs outside the fast mode (embedding, conditioning, VQGAN)"),
             "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
             "achieved_basis": ("SURVEY 8(d) algorithmic GFLOP per image (2 x steps full forwards + decode) / summed GEMM launch time"
                                if algo is not None else "executed GEMM FLOPs / summed GEMM launch time"),
@@ -242,7 +242,6 @@ def main():
     from paella_amd import _lib, synth
     from paella_amd.dist import broadcast_conditioning, conditioning_layout, shard_bounds, shard_inputs
     lib = _lib.load()  # fails loudly if the HIP library is missing
-    paella_amd.set_gemm_precision(a.gemm)
     hooks = {}
     for h in a.hook:
         name, val = h.split("=")
@@ -253,6 +252,7 @@ def main():
     model = paella_amd.Paella(**mcfg)
     unet_sd = synth.randomize_(model, seed=0)
     model = model.to(device)
+    model.set_gemm_precision(a.gemm)  # per-model switch; "fp32" (default) = the exact path
     vq = paella_amd.VQModel(**vcfg)
     vq_sd = synth.randomize_(vq, seed=0)
     vq = vq.to(device)

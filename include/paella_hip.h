@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PAELLA_ABI_VERSION 3
+#define PAELLA_ABI_VERSION 4
 
 #define PAELLA_OK 0
 #define PAELLA_ERR_ARG -1       /* invalid argument / unsupported shape */
@@ -108,12 +108,13 @@ int paella_unet_c_embeddings(paella_unet* m, const float* byt5, int S_byt5, cons
 int paella_unet_r_embedding(paella_unet* m, const float* r, int B, float max_positions, float* r_embed_out,
                             void* stream);
 
-/* OPT-IN fast mode, outside the fp32 parity contract: mode 1 routes every dense contraction whose weight the library owns
- * through bf16-operand MFMA (v_mfma_f32_16x16x32_bf16, fp32 accumulation; activations rounded to bf16 on the way into
- * the matrix cores, weights from a bf16 shadow copy made at finalize).  Mode 0 (default) is the exact fp32 path.
- * Process-wide; returns PAELLA_OK. */
-int paella_set_gemm_precision(int mode);
-int paella_get_gemm_precision(void);
+/* OPT-IN fast mode of ONE model, outside the fp32 parity contract (no process-wide state): mode 1 routes the forward's dense contractions whose K is a
+ * multiple of 64 through bf16-operand MFMA (v_mfma_f32_16x16x32_bf16, fp32 accumulation): bf16 shadow weights (made here / refreshed by finalize), bf16
+ * activations between producer and consumer GEMMs (the 4c-wide MLP hidden tensor, LayerNorm and attention outputs, a bf16 copy of the residual stream where
+ * a LayerNorm-folding GEMM reads it); the residual stream, statistics, attention, logits and the sampling tail stay fp32.  Mode 0 (default) is the exact
+ * fp32 path, bit for bit.  Size workspaces (paella_unet_workspace_bytes) AFTER switching: mode 1 needs room for the bf16 activations. */
+int paella_unet_set_precision(paella_unet* m, int mode, void* stream);
+int paella_unet_get_precision(const paella_unet* m);
 
 /* One denoising evaluation = Paella.forward (src/modules.py:263-275) with the conditioning already prepared.
  * tokens int64 [B,H,W]; r fp32 [B]; attn_weights (utils/alter_attention.py:23-34) fp32 [n_attn_weights] or NULL;

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libpaella_hip.so")
 
 MAX_LEVELS = 8
 MAX_BLOCK_TYPES = 8
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class UnetConfig(Structure):
@@ -78,8 +78,8 @@ SIGNATURES = {
                                     c_void_p, c_size_t, c_void_p]),
     "paella_vqgan_quantize_rows": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "paella_vqgan_lookup_rows": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
-    "paella_set_gemm_precision": (c_int, [c_int]),
-    "paella_get_gemm_precision": (c_int, []),
+    "paella_unet_set_precision": (c_int, [c_void_p, c_int, c_void_p]),
+    "paella_unet_get_precision": (c_int, [c_void_p]),
     "paella_op_gemm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                c_void_p, c_size_t, c_void_p]),
     "paella_op_layernorm": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]),
@@ -95,13 +95,13 @@ TEST_HOOKS = {
     "paella_prof_detail": (c_int64, [c_void_p, c_void_p, c_int64]),
     "paella_prof_enable": (c_int, [c_int]),
     "paella_prof_collect": (c_int, [POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int64)]),
-    "paella_test_register_weight": (c_int, [c_void_p, c_size_t, c_int]),
+    "paella_test_gemm_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "paella_test_gemm_bf16_rule": (c_int, [c_int]),
     "paella_test_launch_chain": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     "paella_test_attention_variant": (c_int, [c_int]),
     "paella_test_gemm_dma": (c_int, [c_int]),
     "paella_test_gemm_raster": (c_int, [c_int]),
     "paella_test_gemm_ring": (c_int, [c_int]),
-    "paella_test_gemm_big": (c_int, [c_int]),
     "paella_test_gemm_big_stagger": (c_int, [c_int]),
     "paella_test_grn_fuse": (c_int, [c_int]),
     "paella_test_ln_fold_ratio": (c_int, [c_float]),

@@ -6,7 +6,7 @@ import hashlib
 import os
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-SOURCES = ["gemm.hip", "gemm_bf16.hip", "elementwise.hip", "dwconv.hip", "attention.hip", "tail.hip", "vqgan.hip", "model.hip", "vqmodel.hip"]
+SOURCES = ["gemm.hip", "elementwise.hip", "dwconv.hip", "attention.hip", "tail.hip", "vqgan.hip", "model.hip", "vqmodel.hip"]
 HEADERS = ["common.h", "internal.h", "gemm_device.h", "philox.h", "test_hooks.h", os.path.join("..", "..", "include", "paella_hip.h")]
 
 

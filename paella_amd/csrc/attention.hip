@@ -21,6 +21,8 @@
 #include <atomic>
 #include <math.h>
 
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));  // bf16 output of the opt-in fast mode (AttnArgs::out16)
+
 // KSPLIT = true : one workgroup per 16 queries, its 4 waves split the key tiles (latency-bound small grids)
 // KSPLIT = false: one workgroup per 64 queries, each wave owns 16 queries and walks all key tiles (K/V re-read 16x less)
 template <int DT, bool KSPLIT>  // DT = head_dim / 16
@@ -140,9 +142,12 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
         const float inv1 = 1.0f / l;
         const int q1 = q0 + r16;
         if (q1 < a.Lq) {
-            float* op = a.out + ((size_t)b * a.Lq + q1) * a.ldo + h * D + kq * 4;
+            const size_t oo = ((size_t)b * a.Lq + q1) * a.ldo + h * D + kq * 4;
 #pragma unroll
-            for (int j = 0; j < DT; ++j) *reinterpret_cast<f32x4*>(op + j * 16) = oacc[j] * inv1;
+            for (int j = 0; j < DT; ++j) {
+                if (a.out16) *reinterpret_cast<bf16x4*>(a.out16 + oo + j * 16) = __builtin_convertvector(oacc[j] * inv1, bf16x4);
+                else *reinterpret_cast<f32x4*>(a.out + oo + j * 16) = oacc[j] * inv1;
+            }
         }
         return;
     }
@@ -171,7 +176,11 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
         f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int w = 0; w < 4; ++w) o += *reinterpret_cast<const f32x4*>(&s_o[w][j][lane][0]) * f[w];
-        if (q < a.Lq) *reinterpret_cast<f32x4*>(a.out + ((size_t)b * a.Lq + q) * a.ldo + h * D + kq * 4 + j * 16) = o * inv;
+        if (q < a.Lq) {
+            const size_t oo = ((size_t)b * a.Lq + q) * a.ldo + h * D + kq * 4 + j * 16;
+            if (a.out16) *reinterpret_cast<bf16x4*>(a.out16 + oo) = __builtin_convertvector(o * inv, bf16x4);
+            else *reinterpret_cast<f32x4*>(a.out + oo) = o * inv;
+        }
     }
 }
 
@@ -333,9 +342,13 @@ __global__ __launch_bounds__(256) void attention_lds_kernel(AttnArgs args) {
     const float inv = 1.0f / l;
     const int q = q0 + r16;
     if (q < Lq) {
-        float* op = args.out + ((size_t)b * Lq + q) * ldo + h * D + kq * 4;
+        const size_t oo = ((size_t)b * Lq + q) * ldo + h * D + kq * 4;
+        unsigned short* const o16 = args.out16;
 #pragma unroll
-        for (int j = 0; j < DT; ++j) *reinterpret_cast<f32x4*>(op + j * 16) = oacc[j] * inv;
+        for (int j = 0; j < DT; ++j) {
+            if (o16) *reinterpret_cast<bf16x4*>(o16 + oo + j * 16) = __builtin_convertvector(oacc[j] * inv, bf16x4);
+            else *reinterpret_cast<f32x4*>(args.out + oo + j * 16) = oacc[j] * inv;
+        }
     }
 }
 

@@ -88,6 +88,9 @@ struct Epilogue {
     float* grn_part_out;
     int grn_rps, grn_np;
     int remap_in, remap_out, remap_off;  // STORE_PLAIN, remap_in > 0: out row = (m/remap_in)*remap_out + m%remap_in + remap_off
+    // optional (STORE_PLAIN only): the stored values rounded to bf16 (RNE) at the same [row, ldc] positions -- the A operand of a consuming bf16 GEMM (opt-in fast
+    // mode).  With GemmArgs::C == nullptr only this copy is written (the 4c-wide hidden tensor of an MLP block never exists in fp32).
+    unsigned short* c16;
 };
 
 static inline Epilogue make_epilogue() {
@@ -95,7 +98,7 @@ static inline Epilogue make_epilogue() {
     e.bias = nullptr; e.act = ACT_NONE; e.alpha = 1.f; e.residual = nullptr; e.ldr = 0;
     e.ts = nullptr; e.ts_stride = 0; e.rows_per_sample = 1; e.rps_div.mul = 0; e.rps_div.shr = 0; e.rps_div.pass = 0xffffffffu; e.store_mode = STORE_PLAIN;
     e.sH = e.sW = e.sC = 0; e.py = e.px = 0; e.n_seg_x = 2; e.remap_in = e.remap_out = e.remap_off = 0; e.sumsq_out = nullptr; e.rowstat_out = nullptr;
-    e.grn_gx_out = nullptr; e.grn_part_out = nullptr; e.grn_rps = 0; e.grn_np = 0;
+    e.grn_gx_out = nullptr; e.grn_part_out = nullptr; e.grn_rps = 0; e.grn_np = 0; e.c16 = nullptr;
     return e;
 }
 
@@ -153,6 +156,11 @@ struct GemmArgs {
     Epilogue ep;
     FusedTail ft;              // used by launch_gemm_tail only
     ConvGather cv;             // cv.enabled: A is an NHWC image gathered on the fly (lda unused, K == ntaps * C)
+    // OPT-IN bf16 fast mode (outside the fp32 parity contract): when BOTH are set the contraction runs on v_mfma_f32_16x16x32_bf16 with fp32 accumulation --
+    // same [M, K] / [N, K] row-major layouts and leading dimensions (in elements) as A / W, both operands straight from HBM to LDS by LDS-DMA.  Needs
+    // K % 64 == 0, lda % 8 == 0, ldw % 8 == 0, no GRN prologue, no implicit convolution.  A / W are then unused (W may stay set for bookkeeping).
+    const unsigned short* A16;
+    const unsigned short* W16;
 };
 
 // Launchers (each returns PAELLA_OK or an error code; all work is enqueued on `stream`).
@@ -171,17 +179,13 @@ int gemm_num_tile_configs();
 // straight from those statistics (GemmArgs::grn_gx): 0 = not applicable (use the grn_from_partials finalize launch)
 int gemm_grn_fused_tile(int M, int C4, int C, int rows_per_sample, bool allow_64);
 // Head GEMM with the fused tail epilogue: one whole tile per workgroup; g.ft.part_* are [M, gemm_tail_tiles_n(M, N)].
-int gemm_tail_tiles_n(int M, int N);
+int gemm_tail_tiles_n(int M, int N, bool bf16_operands = false);
 int launch_gemm_tail(const GemmArgs& g, hipStream_t stream);
 // the tile config launch_gemm_tail uses (the unfused head GEMM is launched with the same one: identical logits bit for bit)
-int gemm_tail_config(int M, int N);
+int gemm_tail_config(int M, int N, bool bf16_operands = false);
 int launch_tail_finalize(const TailArgs& a, const float* part_score, const int* part_idx, int tiles_n, hipStream_t stream);
-// opt-in bf16-operand fast mode (gemm_bf16.hip).  launch_gemm_bf16 returns PAELLA_ERR_STATE when this GEMM has no bf16
-// shadow weight / unsuitable K: the caller falls back to the fp32 kernel.  tile: 0 = 128x128, 1 = 64x64, 2 = 32x32, -1 = choose.
-int launch_gemm_bf16(const GemmArgs& g, int tile, int splitk, void* ws, size_t ws_bytes, hipStream_t stream);
-int gemm_register_weight(const float* base, size_t numel, hipStream_t stream);
-void gemm_unregister_weight(const float* base);
-int gemm_precision();
+// true when a GEMM with these shapes can take the bf16-operand kernels (GemmArgs::A16 / W16)
+static inline bool gemm_bf16_ok(int K, int lda, int ldw) { return K > 0 && (K & 63) == 0 && (lda & 7) == 0 && (ldw & 7) == 0; }
 
 // ln_stats [M, nblk, 2] (per 16-column block (sum, centred M2)) -> out4 [M, 4] = (mean, rstd, mean - (float)mean, |mean| * rstd)
 int launch_ln_rowstat_finalize(const float* stats, int nblk, int K, float eps, float* out4, int64_t M, hipStream_t stream);
@@ -191,11 +195,18 @@ int launch_ln_rowstat_finalize(const float* stats, int nblk, int K, float eps, f
 // s2d != 0: output row (b,y',x') segment (dy,dx) <- input row (b,2y'+dy,2x'+dx); out is [rows/4, 4C].
 int launch_layernorm(const float* x, float* y, int64_t rows, int C, float eps, float g_mul, float g_add,
                      int s2d, int H, int W, hipStream_t stream);
+// the same with an optional bf16 copy of the output (y16; y may then be null) -- A operand of a bf16 GEMM in the opt-in fast mode
+int launch_layernorm16(const float* x, float* y, unsigned short* y16, int64_t rows, int C, float eps, float g_mul, float g_add,
+                       int s2d, int H, int W, hipStream_t stream);
+// bf16 helpers of the opt-in fast mode (elementwise.hip): GRN apply in place on the bf16 hidden tensor, weight shadow copies, row sums of a bf16 matrix
+int launch_grn_apply16(unsigned short* h, const float* scale, const float* shift, int64_t rows, int rows_per_sample, int C, hipStream_t stream);
+int launch_f32_to_bf16(const float* src, unsigned short* dst, size_t n, hipStream_t stream);
+int launch_rowsum_bf16(const unsigned short* W, float* out, int N, int K, hipStream_t stream);
 
 // UNet ResBlock front half: depthwise 3x3 (zero pad) + bias, then LayerNorm over channels.
 // skip != null: grouped 2C->C variant over cat([x, skip]) (reference src/modules.py:46,57).
 int launch_dwconv_ln(const float* x, const float* skip, const float* w, const float* bias, float* y,
-                     int B, int H, int W, int C, float eps, hipStream_t stream);
+                     int B, int H, int W, int C, float eps, hipStream_t stream, unsigned short* y16 = nullptr);  // y16: optional bf16 copy (y may then be null)
 // VQGAN ResBlock depthwise half: y = x + (dw3x3_replicate(xt) + bias) * gamma2.
 int launch_dwconv_res(const float* x, const float* xt, const float* w, const float* bias, float* y,
                       int B, int H, int W, int C, float gamma2, hipStream_t stream);
@@ -225,6 +236,7 @@ int launch_scale_shift(float* x, const float* ts, int ts_stride, int64_t rows, i
 int launch_silu(const float* x, float* y, int64_t n, hipStream_t stream);
 int launch_copy_rows(const float* src, int lds, float* dst, int ldd, int64_t rows, int cols, hipStream_t stream);
 int launch_axpby(float* x, const float* y, float a, float b, int64_t n, hipStream_t stream);  // x = a*x + b*y
+int launch_axpby16(float* x, const float* y, float a, float b, int64_t n, unsigned short* x16, hipStream_t stream);  // + optional bf16 copy of the result
 
 // Attention over [self keys | conditioning keys] (reference src/modules.py:7-19,65-79;
 // utils/alter_attention.py:4-43). q/k/v are column blocks of row-major buffers.
@@ -237,6 +249,7 @@ struct AttnArgs {
     float scale;
     const float* key_weights;         // [n_kw] post-softmax multipliers for the LAST n_kw keys, or null
     int n_kw;
+    unsigned short* out16;            // optional: the output rounded to bf16 at the same [row, ldo] positions INSTEAD of `out` (opt-in fast mode: feeds the out-projection)
 };
 int launch_attention(const AttnArgs& a, hipStream_t stream);
 

@@ -25,7 +25,7 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 template <int NV, bool SKIP>
 __global__ __launch_bounds__(256) void dwconv_ln_block_kernel(const float* __restrict__ x, const float* __restrict__ skip,
                                                               const float* __restrict__ w, const float* __restrict__ bias,
-                                                              float* __restrict__ y, int H, int W, int C, float eps, FastDiv dW, FastDiv dH) {
+                                                              float* __restrict__ y, unsigned short* __restrict__ y16, int H, int W, int C, float eps, FastDiv dW, FastDiv dH) {
     __shared__ float red[4];
     const int64_t pos = blockIdx.x;
     const int C4 = C >> 2;
@@ -88,13 +88,21 @@ __global__ __launch_bounds__(256) void dwconv_ln_block_kernel(const float* __res
             q += (d[0] + d[1]) + (d[2] + d[3]);
         }
     const float rstd = 1.0f / sqrtf(block_sum_256(q, red) / (float)C + eps);
+    if (y16) {  // kernel-uniform: bf16 output for a consuming bf16 GEMM (opt-in fast mode; y may be null then)
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-    for (int i = 0; i < NV; ++i)
-        if (live[i]) *reinterpret_cast<f32x4*>(y + pos * C + (threadIdx.x + i * 256) * 4) = (acc[i] - mean) * rstd;
+        for (int i = 0; i < NV; ++i)
+            if (live[i]) *reinterpret_cast<bf16x4*>(y16 + pos * C + (threadIdx.x + i * 256) * 4) = __builtin_convertvector((acc[i] - mean) * rstd, bf16x4);
+    }
+    if (y) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (live[i]) *reinterpret_cast<f32x4*>(y + pos * C + (threadIdx.x + i * 256) * 4) = (acc[i] - mean) * rstd;
+    }
 }
 
 int launch_dwconv_ln(const float* x, const float* skip, const float* w, const float* bias, float* y, int B, int H,
-                     int W, int C, float eps, hipStream_t st) {
+                     int W, int C, float eps, hipStream_t st, unsigned short* y16) {
     const int64_t total = (int64_t)B * H * W;
     if (total <= 0) return PAELLA_OK;
     if ((C & 3) || (skip && (C & 7)) || C > 8192) { paella_set_error("dwconv_ln: bad channel count %d", C); return PAELLA_ERR_ARG; }
@@ -104,8 +112,8 @@ int launch_dwconv_ln(const float* x, const float* skip, const float* w, const fl
     const FastDiv dW = fast_div_of((unsigned)W), dH = fast_div_of((unsigned)H);
 #define DW_LAUNCH(NVv)                                                                                                   \
     do {                                                                                                                 \
-        if (skip) hipLaunchKernelGGL((dwconv_ln_block_kernel<NVv, true>), grid, block, 0, st, x, skip, w, bias, y, H, W, C, eps, dW, dH); \
-        else hipLaunchKernelGGL((dwconv_ln_block_kernel<NVv, false>), grid, block, 0, st, x, skip, w, bias, y, H, W, C, eps, dW, dH);     \
+        if (skip) hipLaunchKernelGGL((dwconv_ln_block_kernel<NVv, true>), grid, block, 0, st, x, skip, w, bias, y, y16, H, W, C, eps, dW, dH); \
+        else hipLaunchKernelGGL((dwconv_ln_block_kernel<NVv, false>), grid, block, 0, st, x, skip, w, bias, y, y16, H, W, C, eps, dW, dH);     \
     } while (0)
     if (nv <= 1) DW_LAUNCH(1);
     else if (nv <= 2) DW_LAUNCH(2);

@@ -16,6 +16,11 @@ __device__ __forceinline__ float wave_sum(float v) {
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 __device__ __forceinline__ float hsum4(f32x4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
+// bf16 outputs of the opt-in fast mode (the A operands of bf16 GEMMs): round-to-nearest-even, 4 values = 8 bytes
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void st4h(unsigned short* p, f32x4 v) { *reinterpret_cast<bf16x4*>(p) = __builtin_convertvector(v, bf16x4); }
 
 // Normalise NV float4 per lane held in registers: two-pass mean / biased variance (torch LayerNorm semantics).
 template <int NV>
@@ -43,7 +48,7 @@ __device__ __forceinline__ void ln_regs(f32x4 (&v)[NV], int C4, int lane, int C,
 // LayerNorm (reference src/modules.py:22-27 LayerNorm2d; src/vqgan.py:35-39 norm + gamma affine)
 // ---------------------------------------------------------------------------
 template <int NV>
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void layernorm_kernel(const float* __restrict__ x, float* __restrict__ y,
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void layernorm_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned short* __restrict__ y16,
                                                                         int64_t rows, int C, float eps, float g_mul,
                                                                         float g_add, int s2d, int H, int W) {
     const int lane = threadIdx.x & 63;
@@ -58,21 +63,30 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void layernorm_kernel(const f
         v[i] = c4 < C4 ? ld4(xr + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     ln_regs<NV>(v, C4, lane, C, eps, g_mul, g_add);
-    float* yr;
+    int64_t yo;  // element offset of this row's output
     if (s2d) {
         const int64_t hw = (int64_t)H * W;
         const int64_t b = row / hw;
         const int rem = (int)(row - b * hw);
         const int yy = rem / W, xx = rem - yy * W;
         const int64_t orow = (b * (H >> 1) + (yy >> 1)) * (W >> 1) + (xx >> 1);
-        yr = y + orow * (4 * (int64_t)C) + ((yy & 1) * 2 + (xx & 1)) * C;
+        yo = orow * (4 * (int64_t)C) + ((yy & 1) * 2 + (xx & 1)) * C;
     } else {
-        yr = y + row * C;
+        yo = row * C;
     }
+    if (y16) {  // kernel-uniform: the bf16 copy for a consuming bf16 GEMM (y may be null then)
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c4 = lane + i * 64;
-        if (c4 < C4) st4(yr + c4 * 4, v[i]);
+        for (int i = 0; i < NV; ++i) {
+            const int c4 = lane + i * 64;
+            if (c4 < C4) st4h(y16 + yo + c4 * 4, v[i]);
+        }
+    }
+    if (y) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c4 = lane + i * 64;
+            if (c4 < C4) st4(y + yo + c4 * 4, v[i]);
+        }
     }
 }
 
@@ -90,11 +104,15 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void layernorm_kernel(const f
 
 int launch_layernorm(const float* x, float* y, int64_t rows, int C, float eps, float g_mul, float g_add, int s2d,
                      int H, int W, hipStream_t st) {
+    return launch_layernorm16(x, y, nullptr, rows, C, eps, g_mul, g_add, s2d, H, W, st);
+}
+int launch_layernorm16(const float* x, float* y, unsigned short* y16, int64_t rows, int C, float eps, float g_mul, float g_add, int s2d,
+                       int H, int W, hipStream_t st) {
     if (rows <= 0) return PAELLA_OK;
     if (C & 3) { paella_set_error("layernorm: C %% 4 != 0 (C=%d)", C); return PAELLA_ERR_ARG; }
     if (s2d && ((H & 1) || (W & 1))) { paella_set_error("layernorm s2d: odd grid %dx%d", H, W); return PAELLA_ERR_ARG; }
     const unsigned blocks = (unsigned)((rows + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
-    DISPATCH_NV(C >> 2, hipLaunchKernelGGL((layernorm_kernel<NV>), dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, st, x, y,
+    DISPATCH_NV(C >> 2, hipLaunchKernelGGL((layernorm_kernel<NV>), dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, st, x, y, y16,
                                            rows, C, eps, g_mul, g_add, s2d, H, W));
     LAUNCH_CHECK_RET();
     return PAELLA_OK;
@@ -477,15 +495,20 @@ __global__ __launch_bounds__(256) void copy_rows4_kernel(const float* __restrict
     }
 }
 // x = a*x + b*y over n floats (n % 4 == 0): classifier-free-guidance mix of the two halves ahead of the linear head
-__global__ __launch_bounds__(256) void axpby_kernel(float* __restrict__ x, const float* __restrict__ y, float a, float b, int64_t n4) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) st4(x + i * 4, ld4(x + i * 4) * a + ld4(y + i * 4) * b);
+__global__ __launch_bounds__(256) void axpby_kernel(float* __restrict__ x, const float* __restrict__ y, float a, float b, int64_t n4, unsigned short* __restrict__ x16) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const f32x4 v = ld4(x + i * 4) * a + ld4(y + i * 4) * b;
+        st4(x + i * 4, v);
+        if (x16) st4h(x16 + i * 4, v);
+    }
 }
-int launch_axpby(float* x, const float* y, float a, float b, int64_t n, hipStream_t st) {
+int launch_axpby(float* x, const float* y, float a, float b, int64_t n, hipStream_t st) { return launch_axpby16(x, y, a, b, n, nullptr, st); }
+int launch_axpby16(float* x, const float* y, float a, float b, int64_t n, unsigned short* x16, hipStream_t st) {
     if (n <= 0) return PAELLA_OK;
     if (n & 3) { paella_set_error("axpby: n %% 4 != 0"); return PAELLA_ERR_ARG; }
     int64_t blocks = (n / 4 + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, y, a, b, n / 4);
+    hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, y, a, b, n / 4, x16);
     LAUNCH_CHECK_RET();
     return PAELLA_OK;
 }
@@ -503,6 +526,75 @@ int launch_copy_rows(const float* src, int lds_, float* dst, int ldd, int64_t ro
     int64_t blocks = (rows * cols + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, st, src, lds_, dst, ldd, rows, cols);
+    LAUNCH_CHECK_RET();
+    return PAELLA_OK;
+}
+
+// ---------------------------------------------------------------------------
+// bf16 helpers of the opt-in fast mode (outside the fp32 parity contract)
+// ---------------------------------------------------------------------------
+// GlobalResponseNorm apply (reference src/modules.py:40: gamma * (x * Nx) + beta + x = x * scale[b][k] + beta[k]) IN PLACE on the bf16 hidden tensor of an
+// MLP block: the second GEMM then takes a plain operand straight from HBM to LDS (a bf16 operand cannot be transformed on the way).  One 16-byte chunk
+// (8 values) per thread and step; fp32 arithmetic, one rounding on the way back.
+__global__ __launch_bounds__(256) void grn_apply16_kernel(unsigned short* __restrict__ h, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                          unsigned total8, int C8, FastDiv dC8, FastDiv dRps) {
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total8; i += gridDim.x * 256u) {
+        const unsigned row = fast_div(i, dC8);
+        const unsigned c = (i - row * (unsigned)C8) * 8u;
+        const unsigned b = fast_div(row, dRps);
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(h + (size_t)i * 8);
+        const float* sp = scale + (size_t)b * ((size_t)C8 * 8) + c;
+        const f32x4 s0 = ld4(sp), s1 = ld4(sp + 4), t0 = ld4(shift + c), t1 = ld4(shift + c + 4);
+        const f32x8 f = __builtin_convertvector(v, f32x8);
+        f32x8 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o[e] = f[e] * s0[e] + t0[e]; o[4 + e] = f[4 + e] * s1[e] + t1[e]; }
+        *reinterpret_cast<bf16x8*>(h + (size_t)i * 8) = __builtin_convertvector(o, bf16x8);
+    }
+}
+int launch_grn_apply16(unsigned short* h, const float* scale, const float* shift, int64_t rows, int rows_per_sample, int C, hipStream_t st) {
+    if (rows <= 0) return PAELLA_OK;
+    if ((C & 7) || rows * (C / 8) >= 0x7fffffffll || rows_per_sample < 1) { paella_set_error("grn_apply16: C %% 8 != 0 or tensor too large"); return PAELLA_ERR_ARG; }
+    const unsigned total8 = (unsigned)(rows * (C / 8));
+    int64_t blocks = ((int64_t)total8 + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(grn_apply16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, h, scale, shift, total8, C / 8, fast_div_of((unsigned)(C / 8)), fast_div_of((unsigned)rows_per_sample));
+    LAUNCH_CHECK_RET();
+    return PAELLA_OK;
+}
+
+// fp32 -> bf16 (RNE): the shadow copy of a weight matrix, made once per (re)load
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) st4h(dst + i * 4, ld4(src + i * 4));
+}
+int launch_f32_to_bf16(const float* src, unsigned short* dst, size_t n, hipStream_t st) {
+    if (n == 0) return PAELLA_OK;
+    if (n & 3) { paella_set_error("f32_to_bf16: n %% 4 != 0"); return PAELLA_ERR_ARG; }
+    size_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, src, dst, n / 4);
+    LAUNCH_CHECK_RET();
+    return PAELLA_OK;
+}
+// out[n] = sum_k (float)W16[n][k]: the row sums a LayerNorm folded into a bf16 GEMM's epilogue needs -- of the ROUNDED weights, so that
+// rstd * (sum_k a16 W16 - mean * wsum) is the LayerNorm of the rounded operand exactly.  One wave per row, fp32 sums in a fixed order.
+__global__ __launch_bounds__(256) void rowsum_bf16_kernel(const unsigned short* __restrict__ W, float* __restrict__ out, int N, int K) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const unsigned short* w = W + (size_t)n * K;
+    float s = 0.f;
+    for (int k = lane * 8; k < K; k += 64 * 8) {
+        const f32x8 f = __builtin_convertvector(*reinterpret_cast<const bf16x8*>(w + k), f32x8);
+        s += ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
+    }
+    s = wave_sum(s);
+    if (lane == 0) out[n] = s;
+}
+int launch_rowsum_bf16(const unsigned short* W, float* out, int N, int K, hipStream_t st) {
+    if (N <= 0) return PAELLA_OK;
+    if (K & 7) { paella_set_error("rowsum_bf16: K %% 8 != 0"); return PAELLA_ERR_ARG; }
+    hipLaunchKernelGGL(rowsum_bf16_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, W, out, N, K);
     LAUNCH_CHECK_RET();
     return PAELLA_OK;
 }

@@ -39,6 +39,7 @@
 #include <vector>
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 struct SkPlan {
     int tiles_m, tiles_n;  // tile grid
@@ -85,6 +86,11 @@ __device__ __forceinline__ void dma_b128_to_lds(__amdgpu_buffer_rsrc_t rsrc, flo
 #endif
 }
 
+// one 16x16x32 bf16 MFMA on two 16-byte fragments (8 bf16 each: k = 8 * kq .. + 7 of the fragment's 32-wide k group), fp32 accumulate
+__device__ __forceinline__ f32x4 mma_bf16(const f32x4 w, const f32x4 a, const f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, a), c, 0, 0, 0);
+}
+
 #ifdef PAELLA_GEMM_CLOCK_PROBE
 __device__ unsigned long long g_clock_probe[2];  // (shader cycles, 100 MHz wall-clock ticks) of one workgroup of the last launch
 extern "C" int paella_probe_gemm_clock(unsigned long long* out2) {
@@ -94,7 +100,7 @@ extern "C" int paella_probe_gemm_clock(unsigned long long* out2) {
 }
 #endif
 
-template <int WM, int WN, int TM, int TN, int PD, int APRO, bool TAIL = false, int BK = 32, bool DMA = false, int RING = 0>  // BK: K step (32 or 64 floats per LDS row); APRO: 0 none, 1 GRN scale/shift, 2 LayerNorm from row statistics; TAIL: fused sampling tail (head GEMM);
+template <int WM, int WN, int TM, int TN, int PD, int APRO, bool TAIL = false, int BK = 32, bool DMA = false, int RING = 0, bool BF = false>  // BK: K step (32 or 64 floats per LDS row); APRO: 0 none, 1 GRN scale/shift, 2 LayerNorm from row statistics; TAIL: fused sampling tail (head GEMM);
 // DMA: operands that need no transform (W always, A when APRO == 0) go global -> LDS directly (buffer_load ... lds), no staging registers, no ds_write pass
 // APRO 4 (ring tiles only): the GRN apply from the producer's UNFINISHED statistics -- a' = a * (1 + gamma * gx / (mean gx + 1e-6)) + shift, the mean
 // derived per workgroup from the producer's per-column-tile partial sums (no finalize launch between the two MLP GEMMs).
@@ -109,10 +115,15 @@ template <int WM, int WN, int TM, int TN, int PD, int APRO, bool TAIL = false, i
 // stages (two K steps in flight), fragments read one 16-wide k group ahead of the MFMAs that consume them -- including across the K-step barrier -- so
 // neither a ds_read latency nor a store phase ever sits in front of an idle matrix core; the GRN prologue is applied to the fragments from a side
 // stage that holds the scale rows of up to 16 consecutive samples.
+// BF (the OPT-IN bf16 fast mode, outside the fp32 parity contract): both operands are bf16 in HBM (GemmArgs::A16 / W16) and enter the matrix cores as bf16
+// (v_mfma_f32_16x16x32_bf16, fp32 accumulation).  A K step is the same 128 BYTES per row (64 bf16 instead of 32 floats), so the LDS image, the XOR swizzle,
+// the LDS-DMA addressing, the ring, the stream-K decomposition, the slabs and every epilogue are shared with the fp32 instantiation: a lane's ds_read_b128 of
+// slot kk * 4 + kq holds k = kk * 32 + kq * 8 .. + 7 -- exactly its operand of ONE 16x16x32 MFMA where the fp32 kernel issues four 16x16x4 ones.  Only the
+// all-DMA variants exist (direct-to-LDS twins and ring tiles; prologues 0 and 2 -- the folded LayerNorm always takes the fold, there is no operand-side guard).
 __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (WM * WN == 8 ? 1 : TM * TN == 1 ? (RING == 3 ? 5 : 4) : (TM * TN == 2 ? 4 : 3))
                                            : (TAIL && DMA) ? 4  // fused head + tail on the 64x64 direct-to-LDS tile: four independent workgroups per CU
                                            : (TAIL && WM * WN == 8 && TM * TN == 4) ? 4  // fused head + tail on 128x64 tiles: TWO+ workgroups per CU, one's Philox / log epilogue overlaps another's main loop
-                                           : (WM == 2 && WN == 2 && TM * TN == 1 && PD == 2 && BK == 32 && APRO != 1) ? 5
+                                           : (WM == 2 && WN == 2 && TM * TN == 1 && PD == 2 && BK == 32 && (APRO == 0 || APRO == 3)) ? 5  // (GRN / LayerNorm variants spill under 96 registers)
                                            : (DMA && WM * WN == 4 && TM * TN == 16) ? 2  // 128x128 on 4 waves, direct-to-LDS: two independent workgroups per CU (64 KiB of LDS each)
                                            : ((WM * WN == 8 && WM * TM == 8 && WN * TN == 4 && PD == 2 && BK == 32 && APRO == 0 && !TAIL) ? 4 : 1)) void gemm_nt_kernel(GemmArgs g, SkPlan p, float* __restrict__ slabs,
                                                                unsigned* __restrict__ tickets, unsigned slab_bytes) {
@@ -126,6 +137,8 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (WM * WN == 8 ? 1 : TM * T
     static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
     static_assert(PD == 1 || PD == 2, "prefetch ring depth 1 or 2");
     static_assert(BK == 32 || BK == 64, "K step of 32 or 64");
+    static_assert(!BF || ((DMA || RING > 0) && (APRO == 0 || APRO == 2) && BK == 32), "bf16 operands: direct-to-LDS / ring variants, no operand transform");
+    constexpr int ESZ = BF ? 2 : 4;  // bytes per operand element in HBM and LDS
     // Direct-to-LDS operands: one buffer_load_dwordx4 ... lds per wave and 8 tile rows writes 1 KiB at M0 + lane * 16, i.e. LDS stays
     // lane-linear; the XOR swizzle of the 16-byte slots is applied to the SOURCE address instead (lane l of a row fetches chunk
     // (l % 8) ^ (row % 8)).  Needs K % BK == 0 (no activation-side K-tail mask) -- the host picks the register-staged twin otherwise.
@@ -203,15 +216,17 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (WM * WN == 8 ? 1 : TM * T
     // buffer return 0 (hardware range check), so only the M / N clamps remain; the K tail is masked when the tile is staged.
     int ltile = (int)fast_div(u0, p.dKT);
     int lkt = (int)(u0 - (unsigned)ltile * (unsigned)KT);
-    auto rsrc_of = [](const float* ptr, size_t bytes) {
-        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ptr), 0, (int)(bytes > 0xffffffffull ? 0xffffffffull : bytes), 0x00020000);
+    auto rsrc_of = [](const void* ptr, size_t bytes) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, (int)(bytes > 0xffffffffull ? 0xffffffffull : bytes), 0x00020000);
     };
+    const char* const Abase = BF ? reinterpret_cast<const char*>(g.A16) : reinterpret_cast<const char*>(g.A);
+    const char* const Wbase = BF ? reinterpret_cast<const char*>(g.W16) : reinterpret_cast<const char*>(g.W);
     // descriptors are re-based on every tile (first row of the tile / first image of the tile): per-thread offsets stay far below
     // 4 GiB whatever the operand size, and the range check still ends at the true end of each operand
     const size_t a_bytes = APRO == 3 ? (size_t)(g.M / (g.cv.Ho * g.cv.Wo)) * g.cv.Hi * g.cv.Wi * g.cv.C * sizeof(float)
-                                     : ((size_t)(g.M - 1) * g.lda + g.K) * sizeof(float);
-    const size_t w_bytes = ((size_t)(g.N - 1) * g.ldw + g.K) * sizeof(float);
-    __amdgpu_buffer_rsrc_t rsrcA = rsrc_of(g.A, a_bytes), rsrcW = rsrc_of(g.W, w_bytes);
+                                     : ((size_t)(g.M - 1) * g.lda + g.K) * ESZ;
+    const size_t w_bytes = ((size_t)(g.N - 1) * g.ldw + g.K) * ESZ;
+    __amdgpu_buffer_rsrc_t rsrcA = rsrc_of(Abase, a_bytes), rsrcW = rsrc_of(Wbase, w_bytes);
     __amdgpu_buffer_rsrc_t rsrcS = rsrc_of(g.A, 16);
     const __amdgpu_buffer_rsrc_t rsrcT = rsrc_of((APRO == 1 || APRO == 4) ? g.a_shift : g.A, (APRO == 1 || APRO == 4) ? (size_t)g.K * sizeof(float) : 16);
     const __amdgpu_buffer_rsrc_t rsrcG = rsrc_of(APRO == 4 ? g.grn_gamma : g.A, APRO == 4 ? (size_t)g.K * sizeof(float) : 16);
@@ -230,11 +245,11 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (WM * WN == 8 ? 1 : TM * T
             img0 = m0 / (g.cv.Ho * g.cv.Wo);
             a_base = (size_t)img0 * g.cv.Hi * g.cv.Wi * g.cv.C * sizeof(float);
         } else {
-            a_base = (size_t)m0 * g.lda * sizeof(float);
+            a_base = (size_t)m0 * g.lda * ESZ;
         }
-        rsrcA = rsrc_of(reinterpret_cast<const float*>(reinterpret_cast<const char*>(g.A) + a_base), a_bytes - a_base);
-        const size_t w_base = (size_t)n0 * g.ldw * sizeof(float);
-        rsrcW = rsrc_of(reinterpret_cast<const float*>(reinterpret_cast<const char*>(g.W) + w_base), w_bytes - w_base);
+        rsrcA = rsrc_of(Abase + a_base, a_bytes - a_base);
+        const size_t w_base = (size_t)n0 * g.ldw * ESZ;
+        rsrcW = rsrc_of(Wbase + w_base, w_bytes - w_base);
         if (APRO == 1 || APRO == 4) {
             smp0 = (int)fast_div((unsigned)m0, g.a_rps_div);
             const size_t s_bytes = (size_t)(fast_div((unsigned)(g.M - 1), g.a_rps_div) + 1) * g.K * sizeof(float), s_base = (size_t)smp0 * g.K * sizeof(float);
@@ -251,7 +266,7 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (WM * WN == 8 ? 1 : TM * T
                 cx[i] = xo * g.cv.stride;
                 aoff[i] = (unsigned)(bimg - img0) * (unsigned)(g.cv.Hi * g.cv.Wi);  // position index of the image's (0, 0), relative to the tile's first image
             } else {
-                aoff[i] = ((unsigned)(gmc - m0) * (unsigned)g.lda + (unsigned)((DMA_A ? (ldc4 ^ (ldrow & (SL - 1))) : ldc4) * 4)) * 4u;
+                aoff[i] = (unsigned)(gmc - m0) * (unsigned)g.lda * (unsigned)ESZ + (unsigned)((DMA_A ? (ldc4 ^ (ldrow & (SL - 1))) : ldc4) * 16);  // (row, 16-byte slot) in bytes
             }
             if (APRO == 1 && RING == 0) soff[i] = ((unsigned)((int)fast_div((unsigned)gmc, g.a_rps_div) - smp0) * (unsigned)g.K + (unsigned)(ldc4 * 4)) * 4u;
         }
@@ -261,7 +276,7 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (WM * WN == 8 ? 1 : TM * T
             if (BIG) aux_s_off2 = ((unsigned)min(8 + (lane_k >> 3), last) * (unsigned)g.K + (unsigned)((lane_k & 7) * 4)) * 4u;
         }
 #pragma unroll
-        for (int i = 0; i < LB; ++i) boff[i] = ((unsigned)(min(n0 + ldrow + i * RP, g.N - 1) - n0) * (unsigned)g.ldw + (unsigned)((DMA_W ? (ldc4 ^ (ldrow & (SL - 1))) : ldc4) * 4)) * 4u;
+        for (int i = 0; i < LB; ++i) boff[i] = (unsigned)(min(n0 + ldrow + i * RP, g.N - 1) - n0) * (unsigned)g.ldw * (unsigned)ESZ + (unsigned)((DMA_W ? (ldc4 ^ (ldrow & (SL - 1))) : ldc4) * 16);
     };
     set_tile(ltile);
     if (APRO == 3) {
@@ -292,7 +307,7 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (WM * WN == 8 ? 1 : TM * T
                     const int gmc = min(ln_tm * BM + (wm * TM + i) * 16 + r16, g.M - 1);
                     const f32x4 v = *reinterpret_cast<const f32x4*>(g.ln_row + (size_t)gmc * 4);
                     fr_mu[i] = v[0]; fr_rs[i] = v[1]; fr_mu_lo[i] = v[2];
-                    ln_dir[i] = __builtin_amdgcn_ballot_w64(v[3] > g.ln_fold_ratio) != 0;
+                    ln_dir[i] = !BF && __builtin_amdgcn_ballot_w64(v[3] > g.ln_fold_ratio) != 0;
                     ln_any = ln_any || ln_dir[i];
                 }
                 return;
@@ -324,14 +339,14 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (WM * WN == 8 ? 1 : TM * T
                 acc.S += __shfl_xor(acc.S, 32, 64); acc.Q += __shfl_xor(acc.Q, 32, 64); acc.M += __shfl_xor(acc.M, 32, 64);
                 acc.finish(g.K, g.ln_eps, fr_mu[i], fr_rs[i]);
                 fr_mu_lo[i] = (float)(acc.S / (double)g.K - (double)fr_mu[i]);
-                ln_dir[i] = __builtin_amdgcn_ballot_w64(fabsf(fr_mu[i]) * fr_rs[i] > g.ln_fold_ratio) != 0;  // wave-uniform, a function of the block's 16 rows only
+                ln_dir[i] = !BF && __builtin_amdgcn_ballot_w64(fabsf(fr_mu[i]) * fr_rs[i] > g.ln_fold_ratio) != 0;  // wave-uniform, a function of the block's 16 rows only
                 ln_any = ln_any || ln_dir[i];
             }
         }
     };
     // operand-side LayerNorm of an A fragment (row block i, 4 consecutive k from kbase) -- only for blocks flagged by ln_row_stats; zero past K like the staged K tail
     auto ln_fix = [&](f32x4& a, int i, int kbase) __attribute__((always_inline)) {
-        if constexpr (APRO == 2) {
+        if constexpr (APRO == 2 && !BF) {
             if (ln_dir[i]) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) a[e] = (kbase + e < g.K) ? ((a[e] - fr_mu[i]) - fr_mu_lo[i]) * fr_rs[i] : 0.f;
@@ -443,13 +458,18 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (WM * WN == 8 ? 1 : TM * T
     };
     auto mfma_group = [&](auto kk_tag, auto e0_tag, auto e1_tag) __attribute__((always_inline)) {
         constexpr int kk = decltype(kk_tag)::value, e0 = decltype(e0_tag)::value, e1 = decltype(e1_tag)::value;
+        if constexpr (BF) {  // ONE MFMA per (i, j) and k group: the [e0, e1) quarter range selects that share of the TM * TN accumulators
 #pragma unroll
-        for (int e = e0; e < e1; ++e)
+            for (int ij = e0 * TM * TN / 4; ij < e1 * TM * TN / 4; ++ij) acc[ij / TN][ij % TN] = mma_bf16(Fb[kk][ij % TN], Fa[kk][ij / TN], acc[ij / TN][ij % TN]);
+        } else {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int e = e0; e < e1; ++e)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(Fb[kk][j][e], Fa[kk][i][e], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(Fb[kk][j][e], Fa[kk][i][e], acc[i][j], 0, 0, 0);
+        }
     };
     // A 1x1 wave tile alternates two accumulators so its MFMAs are never back-to-back dependent
     // (v_mfma_f32_16x16x4_f32: 32-cycle issue, 40-cycle dependent latency).
@@ -483,7 +503,22 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (WM * WN == 8 ? 1 : TM * T
 #pragma unroll
                     for (int i = 0; i < TM; ++i) ln_fix(af[kk][i], i, kt_cur * BK + (kk * 4 + kq) * 4);
             }
-            if (DUAL) {
+            if constexpr (BF) {
+                if (DUAL) {
+#pragma unroll
+                    for (int kk = 0; kk < KG; kk += 2) {
+                        acc[0][0] = mma_bf16(bf[kk][0], af[kk][0], acc[0][0]);
+                        acc2 = mma_bf16(bf[kk + 1][0], af[kk + 1][0], acc2);
+                    }
+                } else {
+#pragma unroll
+                    for (int kk = 0; kk < KG; ++kk)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j) acc[i][j] = mma_bf16(bf[kk][j], af[kk][i], acc[i][j]);
+                }
+            } else if (DUAL) {
 #pragma unroll
                 for (int kk = 0; kk < KG; kk += 2)
 #pragma unroll
@@ -521,13 +556,20 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (WM * WN == 8 ? 1 : TM * T
 #pragma unroll
                     for (int i = 0; i < TM; ++i) ln_fix(af[i], i, kt_cur * BK + c4 * 4);
                 }
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
+                if constexpr (BF) {
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][e], af[i][e], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < TN; ++j) acc[i][j] = mma_bf16(bf[j], af[i], acc[i][j]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][e], af[i][e], acc[i][j], 0, 0, 0);
+                }
             }
         }
     };
@@ -857,7 +899,22 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (WM * WN == 8 ? 1 : TM * T
                     }
                 }
             }
-            if (TM * TN == 1) {
+            if constexpr (BF) {
+                if (TM * TN == 1) {
+#pragma unroll
+                    for (int kk = 0; kk < KG; kk += 2) {
+                        acc[0][0] = mma_bf16(bf[kk][0], af[kk][0], acc[0][0]);
+                        acc2 = mma_bf16(bf[kk + 1][0], af[kk + 1][0], acc2);
+                    }
+                } else {
+#pragma unroll
+                    for (int kk = 0; kk < KG; ++kk)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j) acc[i][j] = mma_bf16(bf[kk][j], af[kk][i], acc[i][j]);
+                }
+            } else if (TM * TN == 1) {
 #pragma unroll
                 for (int kk = 0; kk < KG; kk += 2)
 #pragma unroll
@@ -1196,15 +1253,6 @@ static void launch_ring(const GemmArgs& g, const SkPlan& p, unsigned G, float* s
         hipLaunchKernelGGL((gemm_nt_kernel<2, 2, TM, TN, 1, 0, false, 32, false, RING>), dim3(G), dim3(256), 0, st, g, p, slabs, tickets, slab_bytes);
 }
 
-static void launch_big(const GemmArgs& g, const SkPlan& p, unsigned G, float* slabs, unsigned* tickets, unsigned slab_bytes, hipStream_t st) {
-    if (g.a_scale)
-        hipLaunchKernelGGL((gemm_nt_kernel<4, 2, 4, 4, 1, 1, false, 32, false, 3>), dim3(G), dim3(512), 0, st, g, p, slabs, tickets, slab_bytes);
-    else if (g.ln_stats)
-        hipLaunchKernelGGL((gemm_nt_kernel<4, 2, 4, 4, 1, 2, false, 32, false, 3>), dim3(G), dim3(512), 0, st, g, p, slabs, tickets, slab_bytes);
-    else
-        hipLaunchKernelGGL((gemm_nt_kernel<4, 2, 4, 4, 1, 0, false, 32, false, 3>), dim3(G), dim3(512), 0, st, g, p, slabs, tickets, slab_bytes);
-}
-
 template <int WM, int WN, int TM, int TN, int PD, int BK>
 static void launch_one(const GemmArgs& g, const SkPlan& p, unsigned G, float* slabs, unsigned* tickets, unsigned slab_bytes, hipStream_t st) {
     constexpr int NT = 64 * WM * WN;
@@ -1241,6 +1289,33 @@ static void launch_one(const GemmArgs& g, const SkPlan& p, unsigned G, float* sl
         hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, PD, 0, false, BK>), dim3(G), dim3(NT), 0, st, g, p, slabs, tickets, slab_bytes);
 }
 
+// ---- bf16 operands (GemmArgs::A16 / W16; the opt-in fast mode): the all-DMA variants of the same kernel ----
+template <int WM, int WN, int TM, int TN, bool DMAv, int RINGv>
+static void launch_bf(const GemmArgs& g, const SkPlan& p, unsigned G, float* slabs, unsigned* tickets, unsigned slab_bytes, hipStream_t st) {
+    constexpr int NT = 64 * WM * WN;
+    if (g.ln_stats)
+        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, 1, 2, false, 32, DMAv, RINGv, true>), dim3(G), dim3(NT), 0, st, g, p, slabs, tickets, slab_bytes);
+    else
+        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, 1, 0, false, 32, DMAv, RINGv, true>), dim3(G), dim3(NT), 0, st, g, p, slabs, tickets, slab_bytes);
+}
+// tile configs that carry a bf16 variant: the direct-to-LDS twins (10, 18, 19) and the ring tiles (30..36)
+static bool bf16_cfg(int cfg) { return cfg == 10 || cfg == 18 || cfg == 19 || (cfg >= 30 && cfg <= 36); }
+static bool launch_bf_cfg(int cfg, const GemmArgs& g, const SkPlan& p, unsigned G, float* slabs, unsigned* tickets, unsigned slab_bytes, hipStream_t st) {
+    switch (cfg) {
+        case 10: launch_bf<2, 4, 4, 2, true, 0>(g, p, G, slabs, tickets, slab_bytes, st); return true;
+        case 18: launch_bf<2, 2, 2, 2, true, 0>(g, p, G, slabs, tickets, slab_bytes, st); return true;
+        case 19: launch_bf<2, 2, 1, 1, true, 0>(g, p, G, slabs, tickets, slab_bytes, st); return true;
+        case 30: launch_bf<2, 2, 1, 1, false, 3>(g, p, G, slabs, tickets, slab_bytes, st); return true;
+        case 31: launch_bf<2, 2, 1, 1, false, 4>(g, p, G, slabs, tickets, slab_bytes, st); return true;
+        case 32: launch_bf<2, 2, 1, 2, false, 3>(g, p, G, slabs, tickets, slab_bytes, st); return true;
+        case 33: launch_bf<2, 2, 2, 1, false, 3>(g, p, G, slabs, tickets, slab_bytes, st); return true;
+        case 34: launch_bf<2, 2, 2, 2, false, 3>(g, p, G, slabs, tickets, slab_bytes, st); return true;
+        case 35: launch_bf<2, 2, 1, 2, false, 4>(g, p, G, slabs, tickets, slab_bytes, st); return true;
+        case 36: launch_bf<4, 2, 4, 4, false, 3>(g, p, G, slabs, tickets, slab_bytes, st); return true;
+        default: return false;
+    }
+}
+
 // ring tiles: both operands by LDS-DMA (whole K steps only), GRN side stage holds the scale rows of at most 8 consecutive samples
 static bool ring_ok(const GemmArgs& g, int BM) {
     if (g.K % 32 || g.cv.enabled) return false;
@@ -1274,14 +1349,6 @@ extern "C" int paella_test_gemm_ring(int cfg) {
     g_gemm_ring = cfg;
     return PAELLA_OK;
 }
-// throughput-regime tile (id 36, 256x128 on 8 waves): 0 = never (the round-3 rules: 64x64 / 128x128 tiles), 1 = launches with >= kBigMinTiles tiles of 256x128
-// (one tile per workgroup), 2 = those + the batched mid-size shapes as ONE persistent workgroup per CU on balanced unit ranges.  Test hook for A/B.
-static std::atomic<int> g_gemm_big{0};
-extern "C" int paella_test_gemm_big(int mode) {
-    if (mode < 0 || mode > 2) { paella_set_error("big-tile mode must be 0, 1 or 2"); return PAELLA_ERR_ARG; }
-    g_gemm_big = mode;
-    return PAELLA_OK;
-}
 static std::atomic<int> g_gemm_big_stagger{1};  // SkPlan::stagger of the 256x128 tile (A/B through the test hook)
 extern "C" int paella_test_gemm_big_stagger(int mode) {
     if (mode < 0 || mode > 2) { paella_set_error("stagger mode must be 0, 1 or 2"); return PAELLA_ERR_ARG; }
@@ -1297,7 +1364,7 @@ extern "C" int paella_test_grn_fuse(int on) { g_grn_fuse = on != 0; return PAELL
 // per sample the 64x32 producer tile (4 parts per tile to combine instead of 2, cross-wave reduction in the epilogue) costs +7.6 us -- more than the
 // launch it removes -- so the model asks with allow_64 = false and keeps the finalize launch there.
 int gemm_grn_fused_tile(int M, int C4, int C, int rows_per_sample, bool allow_64) {
-    if (!g_grn_fuse.load(std::memory_order_relaxed) || !g_gemm_ring.load(std::memory_order_relaxed) || gemm_precision() != 0) return 0;
+    if (!g_grn_fuse.load(std::memory_order_relaxed) || !g_gemm_ring.load(std::memory_order_relaxed)) return 0;
     if ((C & 31) || (C4 & 31) || M % rows_per_sample) return 0;
     const double macs = (double)M * C4 * C;
     const long T64 = (long)((M + 63) / 64) * ((C4 + 63) / 64);
@@ -1317,7 +1384,7 @@ static long ring_resident(int cfg, int apro) {
     }
 }
 
-static void choose_config(int M, int N, int K, int apro, bool ring_allowed, bool big_allowed, int force_ring, size_t slab_cap_bytes, int* cfg_out, unsigned* G_out) {
+static void choose_config(int M, int N, int K, int apro, bool ring_allowed, int force_ring, size_t slab_cap_bytes, int* cfg_out, unsigned* G_out) {
     // one consistent value per decision; force_ring: the caller needs THIS ring tile in the skinny class (its epilogue finishes GRN per tile)
     const int g_gemm_ring = ::g_gemm_ring.load(std::memory_order_relaxed) ? (force_ring > 0 ? force_ring : ::g_gemm_ring.load(std::memory_order_relaxed)) : 0;
     const long ktiles = (K + 31) / 32;
@@ -1325,19 +1392,7 @@ static void choose_config(int M, int N, int K, int apro, bool ring_allowed, bool
     const long T128 = tiles_of_cfg(10, M, N), T64 = tiles_of_cfg(18, M, N), T32 = tiles_of_cfg(5, M, N);
     int cfg;
     long G;
-    const int big_mode = big_allowed ? g_gemm_big.load(std::memory_order_relaxed) : 0;
-    const long T256 = tiles_of_cfg(36, M, N);
-    // one 256x128 tile per workgroup leaves CUs idle in its last round: fraction of the rounds' slots that do work
-    const double big_fill = (double)T256 / (256.0 * (double)((T256 + 255) / 256));
-    if (big_mode >= 1 && (T256 >= 1024 || (T256 >= 224 && big_fill >= 0.85 && macs >= 2.5e9))) {
-        // the throughput regime (batch 32 and up, BASELINE configs[2]): 256x128 tiles on 8 waves, one tile per workgroup = one workgroup per CU; tiles that
-        // run together on an XCD share panels in its L2 (grouped rasterisation), the prefetch ring and the k-group-ahead fragment reads keep the matrix
-        // cores fed (profiles/r04_gemm_big_sweep.txt)
-        cfg = 36; G = T256;
-    } else if (big_mode >= 2 && macs >= 2.5e9 && apro != 2 && T256 >= 64) {
-        // batched mid-size shapes: the same tile as ONE persistent workgroup per CU on balanced (tile, K-step) ranges
-        cfg = 36; G = 256;
-    } else if (T128 >= 1024) {
+    if (T128 >= 1024) {
         // plain operands: 64x64 tiles, 4 independent workgroups per CU, grouped rasterisation (140 TFLOP/s on 32768x5120x1280);
         // with a prologue the 8-wave 128x128 tile stages the A operand half as often and ties or wins
         // (a LayerNorm-consuming GEMM multiplies the raw operand since round 3 -- the normalisation is folded into its epilogue -- and takes the plain rule:
@@ -1359,7 +1414,7 @@ static void choose_config(int M, int N, int K, int apro, bool ring_allowed, bool
     } else {
         // plain operands from 128 rows up: the 1-deep twin whose operands go global -> LDS directly is 2-5 % ahead (profiles/r02_gemm_dma_sweep.txt)
         cfg = (apro == 0 && M >= 128 && K % 32 == 0) ? 19 : 5;
-        long resident = apro == 1 ? 1024 : 1280;  // workgroups that fit at once (see the launch bounds above)
+        long resident = (apro == 1 || apro == 2) ? 1024 : 1280;  // workgroups that fit at once (see the launch bounds above)
         if (g_gemm_ring && ring_allowed) {
             // LDS-DMA ring tiles: 5-15 % ahead of the register-staged / 1-deep tiles on every batch-1 shape in isolation (profiles/r03_gemm_ring_sweep.txt)
             // and 5.4 % per image in the model.  Every launch carries ~6-7 us of fixed latency (boundary, first fetch, publish / ticket / combine,
@@ -1388,6 +1443,50 @@ static void choose_config(int M, int N, int K, int apro, bool ring_allowed, bool
     if (G > U) G = U;
     if (G < 1) G = 1;
     // workspace limits: partial tiles need 2 slab slots per workgroup and one ticket per tile
+    const int BM = kCfgs[cfg].wm * kCfgs[cfg].tm * 16, BN = kCfgs[cfg].wn * kCfgs[cfg].tn * 16;
+    if (G != T) {
+        const size_t slot = (size_t)BM * BN * sizeof(float);
+        if (T > (long)kGemmMaxTickets || slot * 2 > slab_cap_bytes) G = T;
+        else if ((size_t)G * 2 * slot > slab_cap_bytes) G = (long)(slab_cap_bytes / (2 * slot));
+    }
+    *cfg_out = cfg;
+    *G_out = (unsigned)G;
+}
+
+// Tile / workgroup-count choice for bf16 operands (the opt-in fast mode).  The matrix cores run 16x faster on the same LDS bytes, so what a tile costs
+// besides its MFMAs -- fragment reads (a 16x16x32 MFMA is 16 cycles against the 4 + 4 LDS cycles of its two ds_read_b128), LDS-DMA issue, barriers, the
+// epilogue -- decides: the 256x128 tile (id 36: 64x64 wave tiles = half the fragment bytes per MFMA of the 128x128 tile, a quarter of the 64x64 tile's; reads
+// issued one k group ahead) is the throughput tile here although it loses to the 64x64 tile in fp32.  Fitted to tools/gemm_tune.py --bf16 sweeps
+// (profiles/r05_gemm_bf16_tile_sweep.txt).  K steps are 64 elements wide.
+static std::atomic<int> g_bf16_rule{0};  // test hook (A/B of the rules below): bit 0 = never tile 36 (the fp32 rules' tiles instead)
+extern "C" int paella_test_gemm_bf16_rule(int mask) { g_bf16_rule = mask; return PAELLA_OK; }
+static void choose_config_bf16(int M, int N, int K, int apro, size_t slab_cap_bytes, int* cfg_out, unsigned* G_out) {
+    const long ktiles = K / 64;
+    const double macs = (double)M * N * K;
+    const long T256 = tiles_of_cfg(36, M, N), T128 = tiles_of_cfg(10, M, N), T64 = tiles_of_cfg(18, M, N);
+    const bool no_big = (g_bf16_rule.load(std::memory_order_relaxed) & 1) != 0;
+    int cfg;
+    long G;
+    if (!no_big && T256 >= 448) { cfg = 36; G = T256; }
+    else if (T128 >= 1024) { cfg = 10; G = T128; }
+    else if (macs >= 2.5e9) {
+        if (!no_big && T256 >= 32 && apro != 2) { cfg = 36; G = 256; }
+        else if (T128 >= 64) { cfg = 10; G = T128 >= 256 ? T128 : 256; }
+        else { cfg = 18; G = T64 >= 512 ? T64 : 512; }
+    } else {
+        cfg = apro == 2 ? 31 : 30;
+        const long resident = ring_resident(cfg, apro);
+        const long Tc = tiles_of_cfg(cfg, M, N);
+        const long U = Tc * ktiles;
+        if (apro == 2) G = Tc >= 160 ? Tc : 2 * Tc;
+        else G = U / 5;  // ~5 K steps of 64 per workgroup (the fp32 rule's ~10 steps of 32)
+        if (G < Tc) G = Tc;
+        if (G > resident) G = resident;
+    }
+    const long T = tiles_of_cfg(cfg, M, N);
+    const long U = T * ktiles;
+    if (G > U) G = U;
+    if (G < 1) G = 1;
     const int BM = kCfgs[cfg].wm * kCfgs[cfg].tm * 16, BN = kCfgs[cfg].wn * kCfgs[cfg].tn * 16;
     if (G != T) {
         const size_t slot = (size_t)BM * BN * sizeof(float);
@@ -1515,10 +1614,11 @@ static int launch_gemm_cfg_impl(const GemmArgs& g_in, int cfg, int splitk, void*
         paella_set_error("gemm: depth-to-space store needs channels %% 4 == 0");
         return PAELLA_ERR_ARG;
     }
-    if (cfg >= 96 && cfg < 99) return launch_gemm_bf16(g, cfg - 96, splitk, ws, ws_bytes, st);  // explicit bf16 tile (tests / tools)
-    if (cfg < 0 && gemm_precision() == 1) {  // opt-in fast mode: bf16 operands where a shadow weight exists
-        const int rc = launch_gemm_bf16(g, -1, 1, ws, ws_bytes, st);
-        if (rc != PAELLA_ERR_STATE) return rc;
+    const bool bf = g.A16 != nullptr || g.W16 != nullptr;  // opt-in fast mode: bf16 operands, set per launch by the caller (never by a process-wide switch)
+    if (bf && (!g.A16 || !g.W16 || !gemm_bf16_ok(g.K, g.lda, g.ldw) || g.a_scale || g.grn_gx || g.ep.grn_gx_out || g.cv.enabled || (((uintptr_t)g.A16 | (uintptr_t)g.W16) & 15))) {
+        paella_set_error("gemm: bf16 operands need A16 and W16 (16-byte aligned), K %% 64 == 0, lda / ldw %% 8 == 0 and no GRN / convolution prologue (M=%d N=%d K=%d lda=%d ldw=%d)",
+                         g.M, g.N, g.K, g.lda, g.ldw);
+        return PAELLA_ERR_ARG;
     }
     if (g.cv.enabled) {
         if (g.a_scale || g.ln_stats || g.cv.ntaps < 1 || g.cv.ntaps > 16 || (g.cv.C & 31) || g.K != g.cv.ntaps * g.cv.C || g.cv.Ho < 1 || g.cv.Wo < 1 ||
@@ -1530,18 +1630,22 @@ static int launch_gemm_cfg_impl(const GemmArgs& g_in, int cfg, int splitk, void*
     }
     const bool have_ws = ws && ws_bytes > kGemmTicketBytes;
     size_t slab_cap = have_ws ? ws_bytes - kGemmTicketBytes : 0;
-    if (g.ln_stats && !g.ln_row && g.M >= kLnPrepassMinRows && gemm_precision() == 0 && slab_cap >= ((size_t)64 << 20) + (size_t)g.M * 16) {
-        // the finished statistics live at the END of the split-K region (the slabs of this launch, if any, start at its front)
+    if (g.ln_stats && !g.ln_row && g.M >= kLnPrepassMinRows && slab_cap >= ((size_t)80 << 20) + (size_t)g.M * 16) {
+        // the finished statistics live at the END of the split-K region (the slabs of this launch, if any, start at its front); the carve-out is aligned down
+        // whatever ws_bytes the caller passed, and only taken when >= 80 MiB of slab space remain (the largest launch shape, 256 ranges of 256x128 tiles, needs 64)
         const size_t bytes = ((size_t)g.M * 16 + 255) & ~(size_t)255;
-        float* row4 = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + ws_bytes - bytes);
-        slab_cap -= bytes;
+        const size_t row4_off = (ws_bytes - bytes) & ~(size_t)255;
+        float* row4 = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + row4_off);
+        slab_cap = row4_off - kGemmTicketBytes;
         const int rc = launch_ln_rowstat_finalize(g.ln_stats, g.ln_nblk, g.K, g.ln_eps, row4, g.M, st);
         if (rc != PAELLA_OK) return rc;
         g.ln_row = row4;
     }
     unsigned G = 0;
-    if (cfg < 0) {
-        choose_config(g.M, g.N, g.K, (g.a_scale || g.grn_gx) ? 1 : (g.ln_stats ? 2 : 0), ring_ok(g, 64), ring_ok(g, 256) && !g.grn_gx && !g.ep.grn_gx_out, g.force_ring_cfg, slab_cap, &cfg, &G);
+    if (cfg < 0 && bf) {
+        choose_config_bf16(g.M, g.N, g.K, g.ln_stats ? 2 : 0, slab_cap, &cfg, &G);
+    } else if (cfg < 0) {
+        choose_config(g.M, g.N, g.K, (g.a_scale || g.grn_gx) ? 1 : (g.ln_stats ? 2 : 0), ring_ok(g, 64), g.force_ring_cfg, slab_cap, &cfg, &G);
         if (g.cv.enabled && !conv_cfg(cfg)) { paella_set_error("internal: heuristic picked tile %d without a convolution variant", cfg); return PAELLA_ERR_STATE; }
     } else {
         if (cfg >= kNumCfgs) { paella_set_error("gemm: bad tile config %d", cfg); return PAELLA_ERR_ARG; }
@@ -1551,6 +1655,7 @@ static int launch_gemm_cfg_impl(const GemmArgs& g_in, int cfg, int splitk, void*
     }
     const TileCfg& tc = kCfgs[cfg];
     const int BM = tc.wm * tc.tm * 16, BN = tc.wn * tc.tn * 16;
+    if (bf && !bf16_cfg(cfg)) { paella_set_error("gemm: tile config %d has no bf16-operand variant (10, 18, 19, 30..36 do)", cfg); return PAELLA_ERR_ARG; }
     if ((g.grn_gx || g.ep.grn_gx_out) && (!tc.ring || tc.wm * tc.wn == 8)) { paella_set_error("gemm: the in-epilogue / on-load GRN statistics need a ring tile (got tile %d)", cfg); return PAELLA_ERR_STATE; }
     if (g.grn_gx && (!g.grn_gamma || !g.a_shift || !g.grn_part || g.grn_np <= 0 || g.a_scale || g.ln_stats || g.a_rows_per_sample % 16)) {
         paella_set_error("gemm: bad GRN-from-statistics operand description"); return PAELLA_ERR_ARG;
@@ -1564,7 +1669,8 @@ static int launch_gemm_cfg_impl(const GemmArgs& g_in, int cfg, int splitk, void*
     SkPlan p;
     p.tiles_m = (g.M + BM - 1) / BM;
     p.tiles_n = (g.N + BN - 1) / BN;
-    p.KT = (g.K + tc.bk - 1) / tc.bk;
+    const int bk_elems = bf ? 2 * tc.bk : tc.bk;  // a K step is tc.bk * 4 bytes per row
+    p.KT = (g.K + bk_elems - 1) / bk_elems;
     const unsigned long long T = (unsigned long long)p.tiles_m * p.tiles_n;
     const unsigned long long U = T * (unsigned long long)p.KT;
     if (U >= (1ull << 31)) { paella_set_error("gemm: problem too large (%llu work units)", U); return PAELLA_ERR_ARG; }
@@ -1603,6 +1709,11 @@ static int launch_gemm_cfg_impl(const GemmArgs& g_in, int cfg, int splitk, void*
     case id: launch_one<WMv, WNv, TMv, TNv, PDv, 32>(g, p, G, slabs, tickets, slab_bytes, st); break;
 #define GEMM_CASE64(id, WMv, WNv, TMv, TNv, PDv) \
     case id: launch_one<WMv, WNv, TMv, TNv, PDv, 64>(g, p, G, slabs, tickets, slab_bytes, st); break;
+    if (bf) {
+        (void)launch_bf_cfg(cfg, g, p, G, slabs, tickets, slab_bytes, st);
+        LAUNCH_CHECK_RET();
+        return PAELLA_OK;
+    }
     switch (cfg) {
         GEMM_CASE(0, 2, 2, 4, 4, 1)
         GEMM_CASE(1, 2, 2, 4, 2, 2)
@@ -1640,7 +1751,7 @@ static int launch_gemm_cfg_impl(const GemmArgs& g_in, int cfg, int splitk, void*
         case 33: launch_ring<2, 1, 3>(g, p, G, slabs, tickets, slab_bytes, st); break;
         case 34: launch_ring<2, 2, 3>(g, p, G, slabs, tickets, slab_bytes, st); break;
         case 35: launch_ring<1, 2, 4>(g, p, G, slabs, tickets, slab_bytes, st); break;
-        case 36: launch_big(g, p, G, slabs, tickets, slab_bytes, st); break;
+        case 36: paella_set_error("gemm: tile config 36 (256x128) exists for bf16 operands only (in fp32 it measured 4-6 %% behind the 64x64 tile: profiles/r04_gemm_big_tile_sweep.txt)"); return PAELLA_ERR_ARG;
         default: paella_set_error("gemm: bad tile config %d", cfg); return PAELLA_ERR_ARG;
     }
 #undef GEMM_CASE
@@ -1660,9 +1771,9 @@ extern "C" int paella_test_gemm_tail_tile(int cfg) {
     g_tail_tile = cfg;
     return PAELLA_OK;
 }
-int gemm_tail_config(int M, int N) { return tiles_of_cfg(9, M, N) >= 256 ? g_tail_tile.load() : 2; }
-int gemm_tail_tiles_n(int M, int N) {
-    const TileCfg& tc = kCfgs[gemm_tail_config(M, N)];
+int gemm_tail_config(int M, int N, bool bf) { return bf ? 18 : (tiles_of_cfg(9, M, N) >= 256 ? g_tail_tile.load() : 2); }  // (bf16 operands: the 64x64 direct-to-LDS tile only)
+int gemm_tail_tiles_n(int M, int N, bool bf) {
+    const TileCfg& tc = kCfgs[gemm_tail_config(M, N, bf)];
     const int BN = tc.wn * tc.tn * 16;
     return (N + BN - 1) / BN;
 }
@@ -1679,13 +1790,15 @@ static int launch_gemm_tail_impl(const GemmArgs& g, hipStream_t st) {
         paella_set_error("gemm_tail: unsupported arguments (M=%d N=%d K=%d)", g.M, g.N, g.K);
         return PAELLA_ERR_ARG;
     }
-    const int cfg = gemm_tail_config(g.M, g.N);
+    const bool bf = g.A16 != nullptr || g.W16 != nullptr;
+    if (bf && (!g.A16 || !g.W16 || !gemm_bf16_ok(g.K, g.lda, g.ldw))) { paella_set_error("gemm_tail: bf16 operands need A16 and W16, K %% 64 == 0, lda / ldw %% 8 == 0"); return PAELLA_ERR_ARG; }
+    const int cfg = gemm_tail_config(g.M, g.N, bf);
     const TileCfg& tc = kCfgs[cfg];
     const int BM = tc.wm * tc.tm * 16, BN = tc.wn * tc.tn * 16;
     SkPlan p;
     p.tiles_m = (g.M + BM - 1) / BM;
     p.tiles_n = (g.N + BN - 1) / BN;
-    p.KT = (g.K + 31) / 32;
+    p.KT = bf ? g.K / 64 : (g.K + 31) / 32;
     const unsigned long long T = (unsigned long long)p.tiles_m * p.tiles_n;
     if (T * (unsigned long long)p.KT >= (1ull << 31)) { paella_set_error("gemm_tail: problem too large"); return PAELLA_ERR_ARG; }
     p.U = (unsigned)(T * p.KT);
@@ -1702,7 +1815,8 @@ static int launch_gemm_tail_impl(const GemmArgs& g, hipStream_t st) {
     // tiles that run together share an activation panel -- the whole activation matrix crosses the fabric once per column tile (34 GB per launch at configs[2])
     const int raster_gm = g_gemm_raster_gm;
     p.gm = (raster_gm > 0 && BM >= 64 && p.tiles_m >= 4 * raster_gm && p.tiles_n >= 4) ? raster_gm : p.tiles_m;
-    if (cfg == 9) hipLaunchKernelGGL((gemm_nt_kernel<4, 2, 2, 4, 1, 0, true>), dim3((unsigned)G), dim3(512), 0, st, g, p, (float*)nullptr, (unsigned*)nullptr, 0u);
+    if (bf) hipLaunchKernelGGL((gemm_nt_kernel<2, 2, 2, 2, 1, 0, true, 32, true, 0, true>), dim3((unsigned)G), dim3(256), 0, st, g, p, (float*)nullptr, (unsigned*)nullptr, 0u);
+    else if (cfg == 9) hipLaunchKernelGGL((gemm_nt_kernel<4, 2, 2, 4, 1, 0, true>), dim3((unsigned)G), dim3(512), 0, st, g, p, (float*)nullptr, (unsigned*)nullptr, 0u);
     else if (cfg == 14) hipLaunchKernelGGL((gemm_nt_kernel<4, 2, 2, 2, 2, 0, true>), dim3((unsigned)G), dim3(512), 0, st, g, p, (float*)nullptr, (unsigned*)nullptr, 0u);
     else if (cfg == 18 && g.K % 32 == 0 && g_gemm_dma) hipLaunchKernelGGL((gemm_nt_kernel<2, 2, 2, 2, 1, 0, true, 32, true>), dim3((unsigned)G), dim3(256), 0, st, g, p, (float*)nullptr, (unsigned*)nullptr, 0u);
     else hipLaunchKernelGGL((gemm_nt_kernel<2, 2, 2, 2, 2, 0, true>), dim3((unsigned)G), dim3(256), 0, st, g, p, (float*)nullptr, (unsigned*)nullptr, 0u);

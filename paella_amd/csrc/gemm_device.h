@@ -28,7 +28,11 @@ __device__ __forceinline__ void epilogue_write(const Epilogue& ep, float* __rest
     if (ep.store_mode == STORE_PLAIN) {
         size_t orow = m;
         if (ep.remap_in > 0) orow = (size_t)(m / ep.remap_in) * ep.remap_out + (m % ep.remap_in) + ep.remap_off;
-        *reinterpret_cast<f32x4*>(C + orow * ldc + n) = v;
+        if (C) *reinterpret_cast<f32x4*>(C + orow * ldc + n) = v;
+        if (ep.c16) {  // kernel-uniform: bf16 copy (RNE, v_cvt_pk_bf16_f32) for a consuming bf16 GEMM -- opt-in fast mode only
+            typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+            *reinterpret_cast<bf16x4_t*>(ep.c16 + orow * ldc + n) = __builtin_convertvector(v, bf16x4_t);
+        }
     } else {
         const int hw = ep.sH * ep.sW;
         const int b = m / hw;

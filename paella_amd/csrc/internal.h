@@ -16,6 +16,10 @@ struct DevBuf {
     bool loaded = false;
 };
 int devbuf_alloc(DevBuf& b, size_t n);
+struct DevBuf16 {  // bf16 shadow copy of a weight (opt-in fast mode)
+    unsigned short* p = nullptr;
+    size_t n = 0;
+};
 
 // bump allocator over a caller-owned workspace; base == nullptr -> size query only
 struct Arena {
@@ -52,5 +56,6 @@ static inline GemmArgs gemm_args(const float* A, int lda, const float* Wt, int l
     g.ft.temperature = 1.f; g.ft.mode = 0; g.ft.seed = 0; g.ft.seed_ptr = nullptr; g.ft.offset = 0; g.ft.row_offset = 0; g.ft.row_offset_ptr = nullptr;
     g.ft.part_score = nullptr; g.ft.part_idx = nullptr;
     g.cv.enabled = 0;
+    g.A16 = nullptr; g.W16 = nullptr;
     return g;
 }

@@ -77,6 +77,11 @@ struct paella_unet {
     // (composed at finalize), kv_b = in_proj_weight[c:3c] . kv_mapper.1.bias + in_proj_bias[c:3c]; kv_col[i] = first column of block i
     DevBuf kv_w, kv_b;
     std::map<std::string, DevBuf> wsum;  // per LayerNorm-consuming weight (key of the weight tensor): its row sums, for the LayerNorm folded into the GEMM epilogue
+    // OPT-IN bf16 fast mode, PER MODEL (paella_unet_set_precision; outside the fp32 parity contract): bf16 shadow copies of the GEMM weights (made at finalize /
+    // when the mode is switched on) and the row sums of the ROUNDED LayerNorm-consuming weights
+    int precision = 0;                   // 0 = exact fp32 (default), 1 = bf16 operands
+    std::map<std::string, DevBuf16> t16;
+    std::map<std::string, DevBuf> wsum16;
     std::vector<int> kv_col;
     int kv_total = 0;
     int ts_total = 0;
@@ -91,6 +96,12 @@ struct paella_unet {
 static const float* T(const paella_unet* m, const std::string& k) {
     auto it = m->t.find(k);
     return it == m->t.end() ? nullptr : it->second.p;
+}
+// bf16 shadow of a weight, or null (fp32 mode / no shadow for this tensor)
+static const unsigned short* T16(const paella_unet* m, const std::string& k) {
+    if (m->precision != 1) return nullptr;
+    auto it = m->t16.find(k);
+    return it == m->t16.end() ? nullptr : it->second.p;
 }
 
 static void add_spec(paella_unet* m, const std::string& key, Repack kind, std::vector<int64_t> shape, int aux = 0) {
@@ -270,9 +281,11 @@ extern "C" int paella_unet_create(const paella_unet_config* cfg, paella_unet** o
 
 extern "C" void paella_unet_destroy(paella_unet* m) {
     if (!m) return;
-    for (auto& kv : m->t) if (kv.second.p) { gemm_unregister_weight(kv.second.p); (void)hipFree(kv.second.p); }
+    for (auto& kv : m->t) if (kv.second.p) (void)hipFree(kv.second.p);
     for (auto& kv : m->wsum) if (kv.second.p) (void)hipFree(kv.second.p);
-    if (m->kv_w.p) { gemm_unregister_weight(m->kv_w.p); (void)hipFree(m->kv_w.p); }
+    for (auto& kv : m->wsum16) if (kv.second.p) (void)hipFree(kv.second.p);
+    for (auto& kv : m->t16) if (kv.second.p) (void)hipFree(kv.second.p);
+    if (m->kv_w.p) (void)hipFree(m->kv_w.p);
     if (m->kv_b.p) (void)hipFree(m->kv_b.p);
     if (m->ts_w.p) (void)hipFree(m->ts_w.p);
     if (m->ts_b.p) (void)hipFree(m->ts_b.p);
@@ -375,10 +388,75 @@ extern "C" int paella_unet_set_timestep_freqs(paella_unet* m, const float* host_
     return PAELLA_OK;
 }
 
+// bf16 shadow copies of every weight a bf16 GEMM of the forward reads (+ row sums of the rounded LayerNorm-consuming ones), from the tensors as loaded now
+static int make_shadows(paella_unet* m, hipStream_t st) {
+    std::vector<std::pair<std::string, std::pair<int, int>>> ln;  // LayerNorm-consuming weights: key -> (N, K) of the repacked matrix
+    std::vector<std::string> keys;
+    auto want = [&](const Block& b) {
+        switch (b.type) {
+            case BT_RES: case BT_FF:
+                keys.push_back(b.prefix + ".channelwise.0.weight");
+                keys.push_back(b.prefix + ".channelwise.4.weight");
+                break;
+            case BT_ATTN:
+                keys.push_back(b.prefix + ".attention.attn.in_proj_weight");
+                keys.push_back(b.prefix + ".attention.attn.out_proj.weight");
+                if (b.ln_from_stats) ln.push_back({b.prefix + ".attention.attn.in_proj_weight", {3 * b.c, b.c}});
+                break;
+            case BT_DOWN: keys.push_back(b.prefix + ".1.weight"); break;
+            case BT_UP:
+                keys.push_back(b.prefix + ".1.weight");
+                if (b.ln_from_stats) ln.push_back({b.prefix + ".1.weight", {4 * b.c_to, b.c_from}});
+                break;
+            default: break;
+        }
+    };
+    for (const Block& b : m->down) want(b);
+    for (const Block& b : m->up) want(b);
+    keys.push_back("clf.1.weight");
+    keys.push_back("out_mapper.1.weight");
+    if (m->clf_from_stats) ln.push_back({"clf.1.weight", {m->cfg.c_out * m->cfg.patch_size * m->cfg.patch_size, m->cfg.c_hidden[0]}});
+    for (const std::string& k : keys) {
+        auto it = m->t.find(k);
+        if (it == m->t.end() || !it->second.p || (it->second.n & 7)) continue;
+        DevBuf16& d = m->t16[k];
+        if (d.p && d.n != it->second.n) { (void)hipFree(d.p); d.p = nullptr; }
+        if (!d.p) HIP_CHECK_RET(hipMalloc((void**)&d.p, it->second.n * sizeof(unsigned short)));
+        d.n = it->second.n;
+        RET_IF(launch_f32_to_bf16(it->second.p, d.p, d.n, st));
+    }
+    for (auto& t : ln) {
+        auto it = m->t16.find(t.first);
+        if (it == m->t16.end() || (t.second.second & 7)) continue;
+        DevBuf& dst = m->wsum16[t.first];
+        RET_IF(devbuf_alloc(dst, (size_t)t.second.first));
+        RET_IF(launch_rowsum_bf16(it->second.p, dst.p, t.second.first, t.second.second, st));
+    }
+    HIP_CHECK_RET(hipStreamSynchronize(st));
+    return PAELLA_OK;
+}
+
+// OPT-IN fast mode of THIS model (no process-wide state): mode 1 routes the forward's dense contractions whose K is a multiple of 64 through bf16-operand
+// MFMA with fp32 accumulation -- bf16 shadow weights, bf16 activations between producer and consumer GEMMs (the 4c-wide MLP hidden tensor, the LayerNorm /
+// attention outputs, a bf16 copy of the residual stream where a LayerNorm-folding GEMM reads it); the residual stream, statistics, attention, logits and the
+// sampling tail stay fp32.  Workspaces must be sized (paella_unet_workspace_bytes) AFTER the switch.  Mode 0 (default) = the exact path, bit for bit.
+extern "C" int paella_unet_set_precision(paella_unet* m, int mode, void* stream) {
+    if (!m) { paella_set_error("null argument"); return PAELLA_ERR_ARG; }
+    if (mode != 0 && mode != 1) { paella_set_error("precision mode must be 0 (fp32) or 1 (bf16 operands)"); return PAELLA_ERR_ARG; }
+    m->precision = mode;
+    if (mode == 1 && m->finalized) return make_shadows(m, (hipStream_t)stream);
+    if (mode == 0) {
+        HIP_CHECK_RET(hipDeviceSynchronize());  // launches that read the shadows may still be in flight
+        for (auto& kv : m->t16) if (kv.second.p) (void)hipFree(kv.second.p);
+        for (auto& kv : m->wsum16) if (kv.second.p) (void)hipFree(kv.second.p);
+        m->t16.clear(); m->wsum16.clear();
+    }
+    return PAELLA_OK;
+}
+extern "C" int paella_unet_get_precision(const paella_unet* m) { return m ? m->precision : 0; }
+
 extern "C" int paella_unet_finalize(paella_unet* m, void* stream) {
     if (!m) { paella_set_error("null argument"); return PAELLA_ERR_ARG; }
-    for (auto& kv : m->t)  // bf16 shadow copies for the opt-in fast mode are (re)made from the tensors as loaded now
-        if (kv.second.p && kv.second.n >= 4096) RET_IF(gemm_register_weight(kv.second.p, kv.second.n, (hipStream_t)stream));
     for (auto& kv : m->specs) {
         auto it = m->t.find(kv.first);
         if (it == m->t.end() || !it->second.loaded) { paella_set_error("tensor '%s' was never loaded", kv.first.c_str()); return PAELLA_ERR_STATE; }
@@ -427,7 +505,6 @@ extern "C" int paella_unet_finalize(paella_unet* m, void* stream) {
         int total = 0;
         for (int i = 0; i < m->n_attn; ++i) { m->kv_col[i] = total; total += 2 * m->attn_c[i]; }
         m->kv_total = total;
-        if (m->kv_w.p) gemm_unregister_weight(m->kv_w.p);
         RET_IF(devbuf_alloc(m->kv_w, (size_t)total * cc));
         RET_IF(devbuf_alloc(m->kv_b, (size_t)total));
         DevBuf wkv_t;
@@ -455,7 +532,6 @@ extern "C" int paella_unet_finalize(paella_unet* m, void* stream) {
         if (hipStreamSynchronize(st) != hipSuccess && rc == PAELLA_OK) { paella_set_error("finalize: stream error while composing the conditioning projections"); rc = PAELLA_ERR_HIP; }
         if (wkv_t.p) (void)hipFree(wkv_t.p);
         if (rc != PAELLA_OK) return rc;
-        RET_IF(gemm_register_weight(m->kv_w.p, m->kv_w.n, st));
     }
     if (!m->freqs_set) {
         const int half = m->cfg.c_r / 2;
@@ -465,6 +541,7 @@ extern "C" int paella_unet_finalize(paella_unet* m, void* stream) {
         RET_IF(paella_unet_set_timestep_freqs(m, f.data(), half));
     }
     m->finalized = true;
+    if (m->precision == 1) RET_IF(make_shadows(m, (hipStream_t)stream));  // (a reload refreshes the shadows)
     return PAELLA_OK;
 }
 
@@ -482,6 +559,7 @@ struct FwdBuffers {
     float* xl[PAELLA_MAX_LEVELS];
     float* xu[PAELLA_MAX_LEVELS];
     float *h, *g, *grn_scale, *grn_gx, *ts, *remb, *splitk, *rowstat;
+    unsigned short *h16, *g16, *x16;  // bf16 fast mode: the A operands of the bf16 GEMMs (same roles as h, g; x16 = bf16 copy of the current residual stream for LayerNorm-folding consumers)
     // cond_prepare
     float *c_embed, *c_silu;
 };
@@ -520,6 +598,12 @@ static void carve_forward(const paella_unet* m, Arena& a, int B, int H, int W, i
     f.ts = a.take((size_t)B * (m->ts_total > 0 ? m->ts_total : 1));
     f.remb = a.take((size_t)B * c.c_r);
     f.rowstat = a.take(hmax / 8 + 64);  // [rows, C/16, 2]
+    f.h16 = f.g16 = f.x16 = nullptr;
+    if (m->precision == 1) {  // (after everything else: the fp32 layout does not move)
+        f.h16 = reinterpret_cast<unsigned short*>(a.take(hmax / 2 + 64));
+        f.g16 = reinterpret_cast<unsigned short*>(a.take(gmax / 2 + 64));
+        f.x16 = reinterpret_cast<unsigned short*>(a.take(hmax / 2 + 64));
+    }
     (void)S;
 }
 
@@ -636,6 +720,37 @@ static int run_mlp_block(FwdCtx& cx, const Block& b, float* x, const float* skip
     const int ch = b.c;
     const int64_t rows = (int64_t)cx.B * h * w;
     const int rps = h * w;
+    unsigned short* const x16 = (m->precision == 1 && b.emit_rowstat) ? cx.f.x16 : nullptr;  // bf16 copy of the block's output for a LayerNorm-folding bf16 consumer
+    const unsigned short* const w1_16 = T16(m, b.prefix + ".channelwise.0.weight");
+    const unsigned short* const w2_16 = T16(m, b.prefix + ".channelwise.4.weight");
+    if (w1_16 && w2_16 && (ch % 64) == 0 && (rps % 16) == 0) {
+        // ---- OPT-IN bf16 fast mode: depthwise conv + LayerNorm -> bf16 | GEMM1 (bf16 operands) -> GELU -> bf16 hidden + GRN statistics | GRN apply in place on the
+        // bf16 hidden tensor | GEMM2 (bf16 operands) -> fp32 residual stream.  The 4c-wide hidden tensor never exists in fp32.
+        if (b.type == BT_RES)
+            RET_IF(launch_dwconv_ln(x, skip, T(m, b.prefix + ".depthwise.weight"), T(m, b.prefix + ".depthwise.bias"), nullptr, cx.B, h, w, ch, 1e-6f, cx.st, cx.f.h16));
+        else
+            RET_IF(launch_layernorm16(x, nullptr, cx.f.h16, rows, ch, 1e-6f, 1.f, 0.f, 0, 0, 0, cx.st));
+        GemmArgs g1 = gemm_args(nullptr, ch, T(m, b.prefix + ".channelwise.0.weight"), ch, nullptr, 4 * ch, (int)rows, 4 * ch, ch);
+        g1.A16 = cx.f.h16; g1.W16 = w1_16;
+        g1.ep.bias = T(m, b.prefix + ".channelwise.0.bias");
+        g1.ep.act = ACT_GELU;
+        g1.ep.c16 = cx.f.g16;
+        g1.ep.sumsq_out = cx.f.grn_gx;
+        RET_IF(launch_gemm(g1, cx.f.splitk, kSplitKBudget, cx.st));
+        RET_IF(launch_grn_from_partials(cx.f.grn_gx, T(m, b.prefix + ".channelwise.2.gamma"), cx.f.grn_scale, cx.B, rps / 16, 4 * ch, cx.st));
+        RET_IF(launch_grn_apply16(cx.f.g16, cx.f.grn_scale, T(m, b.prefix + ".channelwise.2.beta"), rows, rps, 4 * ch, cx.st));
+        GemmArgs g2 = gemm_args(nullptr, 4 * ch, T(m, b.prefix + ".channelwise.4.weight"), 4 * ch, x, ch, (int)rows, ch, 4 * ch);
+        g2.A16 = cx.f.g16; g2.W16 = w2_16;
+        g2.ep.bias = T(m, b.prefix + ".channelwise.4.bias");
+        g2.ep.residual = x; g2.ep.ldr = ch;
+        g2.ep.c16 = x16;
+        if (b.emit_rowstat) g2.ep.rowstat_out = cx.f.rowstat;
+        if (b.fused_ts >= 0) {
+            g2.ep.ts = cx.f.ts + b.fused_ts; g2.ep.ts_stride = m->ts_total; g2.ep.rows_per_sample = rps;
+        }
+        RET_IF(launch_gemm(g2, cx.f.splitk, kSplitKBudget, cx.st));
+        return PAELLA_OK;
+    }
     if (b.type == BT_RES)
         RET_IF(launch_dwconv_ln(x, skip, T(m, b.prefix + ".depthwise.weight"), T(m, b.prefix + ".depthwise.bias"), cx.f.h, cx.B, h, w, ch, 1e-6f, cx.st));
     else
@@ -643,7 +758,7 @@ static int run_mlp_block(FwdCtx& cx, const Block& b, float* x, const float* skip
     GemmArgs g1 = gemm_args(cx.f.h, ch, T(m, b.prefix + ".channelwise.0.weight"), ch, cx.f.g, 4 * ch, (int)rows, 4 * ch, ch);
     g1.ep.bias = T(m, b.prefix + ".channelwise.0.bias");
     g1.ep.act = ACT_GELU;
-    const int fused_tile = (rps % 16 == 0) ? gemm_grn_fused_tile((int)rows, 4 * ch, ch, rps, false) : 0;
+    const int fused_tile = (rps % 16 == 0 && m->precision == 0) ? gemm_grn_fused_tile((int)rows, 4 * ch, ch, rps, false) : 0;
     if (fused_tile) {
         // GlobalResponseNorm with NO launch of its own (batch-1 regime): GEMM1's tiles cover whole samples, so its epilogue finishes
         // Gx[b][k] = ||g[b, :, k]||_2 and leaves per-column-tile sums of Gx; GEMM2 derives mean_k Gx from those and applies
@@ -680,6 +795,7 @@ static int run_mlp_block(FwdCtx& cx, const Block& b, float* x, const float* skip
     g2.a_rows_per_sample = rps;
     g2.ep.bias = T(m, b.prefix + ".channelwise.4.bias");
     g2.ep.residual = x; g2.ep.ldr = ch;
+    g2.ep.c16 = x16;  // (bf16 mode, block not eligible for the bf16 GEMMs: the consumer may still be)
     if (b.emit_rowstat) g2.ep.rowstat_out = cx.f.rowstat;
     if (b.fused_ts >= 0) {
         g2.ep.ts = cx.f.ts + b.fused_ts; g2.ep.ts_stride = m->ts_total; g2.ep.rows_per_sample = rps;
@@ -697,9 +813,17 @@ static int run_attn_block(FwdCtx& cx, const Block& b, float* x, int h, int w) {
     const bool self = m->cfg.self_attn != 0;
     const int nq = self ? 3 * ch : ch;
     GemmArgs gq = gemm_args(cx.f.h, ch, T(m, b.prefix + ".attention.attn.in_proj_weight"), ch, cx.f.g, nq, (int)rows, nq, ch);
+    // opt-in bf16 fast mode: both projections on bf16 operands (bf16 copy of the residual stream / bf16 LayerNorm output in, bf16 attention output in); q, k, v and
+    // the attention itself stay fp32
+    const unsigned short* const wq16 = (ch % 64) == 0 ? T16(m, b.prefix + ".attention.attn.in_proj_weight") : nullptr;
+    const unsigned short* const wo16 = (ch % 64) == 0 ? T16(m, b.prefix + ".attention.attn.out_proj.weight") : nullptr;
     if (b.ln_from_stats) {  // LayerNorm folded into the in-projection's operand load (statistics from the producer's epilogue)
         gq.A = x; gq.ln_stats = cx.f.rowstat; gq.ln_nblk = ch / 16; gq.ln_eps = 1e-6f;
         gq.ln_wsum = m->wsum.at(b.prefix + ".attention.attn.in_proj_weight").p;
+        if (wq16) { gq.A16 = cx.f.x16; gq.W16 = wq16; gq.ln_wsum = m->wsum16.at(b.prefix + ".attention.attn.in_proj_weight").p; }
+    } else if (wq16) {
+        RET_IF(launch_layernorm16(x, nullptr, cx.f.h16, rows, ch, 1e-6f, 1.f, 0.f, 0, 0, 0, cx.st));
+        gq.A16 = cx.f.h16; gq.W16 = wq16;
     } else {
         RET_IF(launch_layernorm(x, cx.f.h, rows, ch, 1e-6f, 1.f, 0.f, 0, 0, 0, cx.st));
     }
@@ -714,10 +838,13 @@ static int run_attn_block(FwdCtx& cx, const Block& b, float* x, int h, int w) {
     a.B = cx.B; a.nhead = nh; a.D = ch / nh; a.Lq = h * w; a.Lself = self ? h * w : 0; a.Lcond = cx.S;
     a.scale = 1.0f / sqrtf((float)(ch / nh));
     a.key_weights = cx.attn_w; a.n_kw = cx.n_aw;
+    a.out16 = wo16 ? cx.f.h16 : nullptr;
     RET_IF(launch_attention(a, cx.st));
     GemmArgs go = gemm_args(cx.f.h, ch, T(m, b.prefix + ".attention.attn.out_proj.weight"), ch, x, ch, (int)rows, ch, ch);
+    if (wo16) { go.A16 = cx.f.h16; go.W16 = wo16; }
     go.ep.bias = T(m, b.prefix + ".attention.attn.out_proj.bias");
     go.ep.residual = x; go.ep.ldr = ch;
+    if (m->precision == 1 && b.emit_rowstat) go.ep.c16 = cx.f.x16;
     if (b.emit_rowstat) go.ep.rowstat_out = cx.f.rowstat;
     RET_IF(launch_gemm(go, cx.f.splitk, kSplitKBudget, cx.st));
     return PAELLA_OK;
@@ -807,15 +934,22 @@ static int unet_forward_impl(paella_unet* m, const int64_t* tokens, const float*
                 const int sc = c.c_hidden[lvl] / 16 * 2;
                 if (f.rowstat && c.c_hidden[lvl] % 16 == 0)
                     RET_IF(launch_copy_rows(f.rowstat, sc, f.rowstat + (size_t)rep * rows_c * sc, sc, rows_c, sc, st));
+                if (f.x16 && c.c_hidden[lvl] % 8 == 0) {  // bf16 fast mode: the bf16 copy of the current activation, as rows of c / 2 floats
+                    const int c2 = c.c_hidden[lvl] / 2;
+                    RET_IF(launch_copy_rows(reinterpret_cast<const float*>(f.x16), c2, reinterpret_cast<float*>(f.x16) + (size_t)rep * rows_c * c2, c2, rows_c, c2, st));
+                }
             }
             B = Bfull; cx.B = Bfull;
         }
         switch (b.type) {
             case BT_DOWN: {  // LayerNorm2d + Conv2d(k2,s2): LN fused with the space-to-depth gather, then a GEMM
                 const int64_t rows_in = (int64_t)B * h * w;
-                RET_IF(launch_layernorm(x, f.h, rows_in, b.c_from, 1e-6f, 1.f, 0.f, 1, h, w, st));
+                const unsigned short* const w16 = ((4 * b.c_from) % 64) == 0 ? T16(m, b.prefix + ".1.weight") : nullptr;
+                if (w16) RET_IF(launch_layernorm16(x, nullptr, f.h16, rows_in, b.c_from, 1e-6f, 1.f, 0.f, 1, h, w, st));
+                else RET_IF(launch_layernorm(x, f.h, rows_in, b.c_from, 1e-6f, 1.f, 0.f, 1, h, w, st));
                 h >>= 1; w >>= 1;
                 GemmArgs g = gemm_args(f.h, 4 * b.c_from, T(m, b.prefix + ".1.weight"), 4 * b.c_from, f.xl[b.level], b.c_to, (int)(rows_in / 4), b.c_to, 4 * b.c_from);
+                if (w16) { g.A16 = f.h16; g.W16 = w16; }
                 g.ep.bias = T(m, b.prefix + ".1.bias");
                 RET_IF(launch_gemm(g, f.splitk, kSplitKBudget, st));
                 x = f.xl[b.level];
@@ -838,8 +972,14 @@ static int unet_forward_impl(paella_unet* m, const int64_t* tokens, const float*
                 const int64_t rows_in = (int64_t)B * h * w;
                 float* dst = f.xu[b.level - 1];
                 GemmArgs g = gemm_args(f.h, b.c_from, T(m, b.prefix + ".1.weight"), b.c_from, dst, b.c_to, (int)rows_in, 4 * b.c_to, b.c_from);
-                if (b.ln_from_stats) { g.A = x; g.ln_stats = f.rowstat; g.ln_nblk = b.c_from / 16; g.ln_eps = 1e-6f; g.ln_wsum = m->wsum.at(b.prefix + ".1.weight").p; }
-                else RET_IF(launch_layernorm(x, f.h, rows_in, b.c_from, 1e-6f, 1.f, 0.f, 0, 0, 0, st));
+                const unsigned short* const w16 = (b.c_from % 64) == 0 ? T16(m, b.prefix + ".1.weight") : nullptr;
+                if (b.ln_from_stats) {
+                    g.A = x; g.ln_stats = f.rowstat; g.ln_nblk = b.c_from / 16; g.ln_eps = 1e-6f; g.ln_wsum = m->wsum.at(b.prefix + ".1.weight").p;
+                    if (w16) { g.A16 = f.x16; g.W16 = w16; g.ln_wsum = m->wsum16.at(b.prefix + ".1.weight").p; }
+                } else if (w16) {
+                    RET_IF(launch_layernorm16(x, nullptr, f.h16, rows_in, b.c_from, 1e-6f, 1.f, 0.f, 0, 0, 0, st));
+                    g.A16 = f.h16; g.W16 = w16;
+                } else RET_IF(launch_layernorm(x, f.h, rows_in, b.c_from, 1e-6f, 1.f, 0.f, 0, 0, 0, st));
                 g.ep.bias = T(m, b.prefix + ".1.bias");
                 g.ep.store_mode = STORE_D2S; g.ep.sH = h; g.ep.sW = w; g.ep.sC = b.c_to; g.ep.n_seg_x = 2;
                 RET_IF(launch_gemm(g, f.splitk, kSplitKBudget, st));
@@ -861,28 +1001,35 @@ static int unet_forward_impl(paella_unet* m, const int64_t* tokens, const float*
         const int p2 = p * p;
         const int64_t n0 = (int64_t)B * h0 * w0;  // full batch again
         GemmArgs g = gemm_args(f.h, c.c_hidden[0], T(m, "clf.1.weight"), c.c_hidden[0], f.g, c.c_out, (int)n0, c.c_out * p2, c.c_hidden[0]);
-        if (m->clf_from_stats) { g.A = x; g.ln_stats = f.rowstat; g.ln_nblk = c.c_hidden[0] / 16; g.ln_eps = 1e-6f; g.ln_wsum = m->wsum.at("clf.1.weight").p; }
-        else RET_IF(launch_layernorm(x, f.h, n0, c.c_hidden[0], 1e-6f, 1.f, 0.f, 0, 0, 0, st));
+        const unsigned short* const wc16 = (c.c_hidden[0] % 64) == 0 ? T16(m, "clf.1.weight") : nullptr;
+        if (m->clf_from_stats) {
+            g.A = x; g.ln_stats = f.rowstat; g.ln_nblk = c.c_hidden[0] / 16; g.ln_eps = 1e-6f; g.ln_wsum = m->wsum.at("clf.1.weight").p;
+            if (wc16) { g.A16 = f.x16; g.W16 = wc16; g.ln_wsum = m->wsum16.at("clf.1.weight").p; }
+        } else if (wc16) {
+            RET_IF(launch_layernorm16(x, nullptr, f.h16, n0, c.c_hidden[0], 1e-6f, 1.f, 0.f, 0, 0, 0, st));
+            g.A16 = f.h16; g.W16 = wc16;
+        } else RET_IF(launch_layernorm(x, f.h, n0, c.c_hidden[0], 1e-6f, 1.f, 0.f, 0, 0, 0, st));
         g.ep.bias = T(m, "clf.1.bias");
         if (p == 2) { g.ep.store_mode = STORE_D2S; g.ep.sH = h0; g.ep.sW = w0; g.ep.sC = c.c_out; g.ep.n_seg_x = 2; }
         RET_IF(launch_gemm(g, f.splitk, kSplitKBudget, st));
         int64_t nt = (int64_t)B * H * W;
-        RET_IF(launch_layernorm(f.g, f.h, nt, c.c_out, 1e-6f, 1.f, 0.f, 0, 0, 0, st));
+        const unsigned short* const wh16 = (c.c_out % 64) == 0 ? T16(m, "out_mapper.1.weight") : nullptr;  // bf16 fast mode: the head GEMM on bf16 operands
+        if (wh16 && !mix) RET_IF(launch_layernorm16(f.g, nullptr, f.h16, nt, c.c_out, 1e-6f, 1.f, 0.f, 0, 0, 0, st));
+        else RET_IF(launch_layernorm(f.g, f.h, nt, c.c_out, 1e-6f, 1.f, 0.f, 0, 0, 0, st));
         if (mix) {  // the head is linear and bias-free: mix its input instead of its output
             nt /= 2;
-            RET_IF(launch_axpby(f.h, f.h + (size_t)nt * c.c_out, mix_c, mix_u, nt * c.c_out, st));
+            RET_IF(launch_axpby16(f.h, f.h + (size_t)nt * c.c_out, mix_c, mix_u, nt * c.c_out, wh16 ? f.h16 : nullptr, st));
         }
         GemmArgs go = gemm_args(f.h, c.c_out, T(m, "out_mapper.1.weight"), c.c_out, logits_out, c.num_labels, (int)nt, c.num_labels, c.c_out);
+        if (wh16) { go.A16 = f.h16; go.W16 = wh16; }
         if (!tail) {
             // same tile config as the fused-tail launch below (one whole tile per workgroup, no K split): the two paths produce
-            // bit-identical logits, hence identical tokens
-            // (the opt-in bf16 fast mode has no parity contract with the fused path: it keeps the heuristic, which routes to the bf16 kernel)
-            if (gemm_precision() == 1) RET_IF(launch_gemm(go, f.splitk, kSplitKBudget, st));
-            else RET_IF(launch_gemm_cfg(go, gemm_tail_config((int)nt, c.num_labels), 1, f.splitk, kSplitKBudget, st));
+            // bit-identical logits, hence identical tokens (also in the bf16 fast mode: both run the bf16 64x64 direct-to-LDS tile)
+            RET_IF(launch_gemm_cfg(go, gemm_tail_config((int)nt, c.num_labels, wh16 != nullptr), 1, f.splitk, kSplitKBudget, st));
         } else {
             // out_mapper fused with the sampling tail (reference src/utils.py:44-50 materialises the logits; here they never leave
             // the registers): per row and column tile the best (score, label) lands in f.g (free after the LayerNorm above)
-            const int tn = gemm_tail_tiles_n((int)nt, c.num_labels);
+            const int tn = gemm_tail_tiles_n((int)nt, c.num_labels, wh16 != nullptr);
             if (tn > (c.num_labels + 63) / 64) { paella_set_error("internal: fused tail tiles narrower than 64 labels (tiles_n=%d)", tn); return PAELLA_ERR_STATE; }
             if (tail->rows != nt || tail->L != c.num_labels) { paella_set_error("fused tail: row / label count mismatch"); return PAELLA_ERR_ARG; }
             go.C = nullptr;
@@ -1012,10 +1159,20 @@ extern "C" int paella_test_mlp_grn_fused(const float* h, const float* W1, const 
     g2.grn_gx = gx; g2.grn_part = part; g2.grn_np = np; g2.grn_gamma = gamma; g2.a_shift = beta; g2.a_rows_per_sample = rps;
     return launch_gemm(g2, ws, ws_bytes, st);
 }
-extern "C" int paella_test_register_weight(const float* w, size_t numel, int on) {
-    if (on) return gemm_register_weight(w, numel, 0);
-    gemm_unregister_weight(w);
-    return PAELLA_OK;
+// test hook (test_hooks.h): one GEMM on bf16 operands (bit patterns supplied by the caller) with an explicit tile config / workgroup count;
+// ln_stats != null folds a LayerNorm of the A rows into the epilogue (row sums of W16 computed here); C16 != null also stores the bf16 copy
+extern "C" int paella_test_gemm_bf16(const unsigned short* A16, const unsigned short* W16, const float* bias, const float* residual, float* C, unsigned short* C16,
+                                     int M, int N, int K, int act, const float* ln_stats, int tile_cfg, int splitk, void* ws, size_t ws_bytes, void* stream) {
+    GemmArgs g = gemm_args(nullptr, K, nullptr, K, C, N, M, N, K);
+    g.A16 = A16; g.W16 = W16;
+    g.ep.bias = bias; g.ep.act = act; g.ep.residual = residual; g.ep.ldr = N; g.ep.c16 = C16;
+    if (ln_stats) {
+        static DevBuf wsum;
+        if (wsum.n < (size_t)N) RET_IF(devbuf_alloc(wsum, (size_t)N));
+        RET_IF(launch_rowsum_bf16(W16, wsum.p, N, K, (hipStream_t)stream));
+        g.ln_stats = ln_stats; g.ln_nblk = K / 16; g.ln_eps = 1e-6f; g.ln_wsum = wsum.p;
+    }
+    return launch_gemm_cfg(g, tile_cfg, splitk, ws, ws_bytes, (hipStream_t)stream);
 }
 extern "C" int paella_op_layernorm(const float* x, float* y, int64_t rows, int C, float eps, void* stream) {
     return launch_layernorm(x, y, rows, C, eps, 1.f, 0.f, 0, 0, 0, (hipStream_t)stream);
@@ -1035,6 +1192,6 @@ extern "C" int paella_op_attention(const float* q, const float* k_self, const fl
     const int ld = nhead * D;
     a.q = q; a.ldq = ld; a.k_self = k_self; a.v_self = v_self; a.ld_self = ld; a.k_cond = k_cond; a.v_cond = v_cond; a.ld_cond = ld;
     a.out = out; a.ldo = ld; a.B = B; a.nhead = nhead; a.D = D; a.Lq = Lq; a.Lself = Lself; a.Lcond = Lcond;
-    a.scale = 1.0f / sqrtf((float)D); a.key_weights = key_weights; a.n_kw = key_weights ? n_kw : 0;
+    a.scale = 1.0f / sqrtf((float)D); a.key_weights = key_weights; a.n_kw = key_weights ? n_kw : 0; a.out16 = nullptr;
     return launch_attention(a, (hipStream_t)stream);
 }

@@ -8,8 +8,13 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
-/* (un)register an arbitrary fp32 [N,K] matrix for the bf16 fast mode so paella_op_gemm(tile_cfg 96..98) can use it */
-int paella_test_register_weight(const float* w, size_t numel, int on);
+/* one GEMM on bf16 operands (the opt-in fast mode's kernels: bit patterns A16 [M,K], W16 [N,K] supplied by the caller) with an explicit tile config
+ * (10, 18, 19, 30..36; < 0 = heuristic) / workgroup count as paella_op_gemm; ln_stats != NULL: LayerNorm of the A rows folded into the epilogue from
+ * [M, K/16, 2] (sum, centred M2) partials; C16 != NULL: also store the result rounded to bf16 (C may then be NULL) */
+int paella_test_gemm_bf16(const unsigned short* A16, const unsigned short* W16, const float* bias, const float* residual, float* C, unsigned short* C16,
+                          int M, int N, int K, int act, const float* ln_stats, int tile_cfg, int splitk, void* ws, size_t ws_bytes, void* stream);
+/* A/B of the bf16 tile rules: bit 0 = never the 256x128 tile (the fp32 rules' tiles instead) */
+int paella_test_gemm_bf16_rule(int mask);
 /* launches n_launches dependent, nearly empty kernels (blocks x 256 threads touching n_elems floats): boundary floor */
 int paella_test_launch_chain(float* buf, int n_elems, int blocks, int n_launches, void* stream);
 /* 1 = run large-query-count attention on the register-fed kernel instead of the LDS-staged one (A/B probe, tools/attn_probe.py) */
@@ -27,13 +32,11 @@ int paella_test_mlp_grn_fused(const float* h, const float* W1, const float* b1, 
 int paella_test_gemm_dma(int on);
 /* the LDS-DMA ring tile (config id 30..35) the launch heuristic uses for the skinny batch-1 shapes; 0 = the register-staged / 1-deep kernels (A/B) */
 int paella_test_gemm_ring(int cfg);
-/* tile of the fused head GEMM + sampling tail: 9 = 128x128, 14 = 128x64 on 8 waves (several workgroups per CU), 18 = 64x64 direct-to-LDS (four workgroups per CU) */
+/* tile of the fused head GEMM + sampling tail: 9 = 128x128, 14 = 128x64 on 8 waves (several workgroups per CU), 18 = 64x64 direct-to-LDS (four workgroups per CU; default) */
 int paella_test_gemm_tail_tile(int cfg);
 /* tile rows per rasterisation group of the GEMM (default 8); 0 = plain m-fastest tile order (A/B) */
 int paella_test_gemm_raster(int gm);
-/* throughput-regime tile (id 36, 256x128 on 8 waves): 0 = never (round-3 rules), 1 = only launches with many tiles, 2 = also the batched mid-size shapes (default) */
-int paella_test_gemm_big(int mode);
-/* 256x128 tile: which of the two waves that share a SIMD runs its LDS-DMA issue / fragment reads late (under the other one's MFMA block): 0 = neither
+/* 256x128 tile (bf16 operands only): which of the two waves that share a SIMD runs its LDS-DMA issue / fragment reads late (under the other one's MFMA block): 0 = neither
  * (both straight after the barrier), 1 = waves 4..7 (default), 2 = odd waves */
 int paella_test_gemm_big_stagger(int mode);
 /* |mean| / std above which a 16-row block of a LayerNorm-consuming GEMM normalises its operand fragments instead of folding the LayerNorm into the

@@ -134,10 +134,10 @@ extern "C" int paella_vqgan_create(const paella_vqgan_config* cfg, paella_vqgan*
 
 extern "C" void paella_vqgan_destroy(paella_vqgan* v) {
     if (!v) return;
-    for (auto& kv : v->t) if (kv.second.p) { gemm_unregister_weight(kv.second.p); (void)hipFree(kv.second.p); }
+    for (auto& kv : v->t) if (kv.second.p) (void)hipFree(kv.second.p);
     for (auto* seq : {&v->enc, &v->dec})
         for (auto& b : *seq)
-            for (auto& pw : b.phase_w) if (pw.p) { gemm_unregister_weight(pw.p); (void)hipFree(pw.p); }
+            for (auto& pw : b.phase_w) if (pw.p) (void)hipFree(pw.p);
     if (v->bn_scale.p) (void)hipFree(v->bn_scale.p);
     if (v->bn_shift.p) (void)hipFree(v->bn_shift.p);
     delete v;
@@ -202,11 +202,6 @@ extern "C" int paella_vqgan_finalize(paella_vqgan* v, void* stream) {
             }
         }
     HIP_CHECK_RET(hipStreamSynchronize(st));
-    for (auto& kv : v->t)  // bf16 shadow copies for the opt-in fast mode
-        if (kv.second.p && kv.second.n >= 4096) RET_IF(gemm_register_weight(kv.second.p, kv.second.n, st));
-    for (auto* seq : {&v->enc, &v->dec})
-        for (auto& b : *seq)
-            for (auto& pw : b.phase_w) if (pw.p && pw.n >= 4096) RET_IF(gemm_register_weight(pw.p, pw.n, st));
     v->finalized = true;
     return PAELLA_OK;
 }

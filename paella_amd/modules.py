@@ -143,6 +143,7 @@ class Paella(nn.Module):
         self._handle = None
         self._loaded_sig = None
         self._ws = None
+        self._precision = 0
         # Constructed in EVAL mode (an nn.Module normally starts in train mode): eval = the hand-written HIP engine, which is what
         # sampling needs; `model.train()` -- the switch the reference's training loops flip (src/train.py:47,
         # src_distributed/train.py:73,140,172) -- selects the differentiable torch-op evaluation of paella_amd/training.py.
@@ -237,6 +238,8 @@ class Paella(nn.Module):
                 freqs = torch.arange(half).float().mul(-emb).exp().contiguous()
                 arr = (ctypes.c_float * half)(*freqs.tolist())
                 _lib.check(lib.paella_unet_set_timestep_freqs(self._handle, arr, half))
+                if self._precision:
+                    _lib.check(lib.paella_unet_set_precision(self._handle, self._precision, _lib.stream_ptr(dev)))
             st = _lib.stream_ptr(dev)
             for key, t in self.state_dict().items():
                 t = t.detach()
@@ -248,6 +251,26 @@ class Paella(nn.Module):
             torch.cuda.current_stream(dev).synchronize()  # staging copies above may be temporaries
         self._loaded_sig = sig
         return self._handle
+
+    def set_gemm_precision(self, mode):
+        """OPT-IN fast mode of THIS model, outside the fp32 parity contract (include/paella_hip.h: paella_unet_set_precision): "bf16" runs the
+        forward's dense contractions on bf16-operand MFMA with fp32 accumulation (bf16 shadow weights, bf16 activations between producer and
+        consumer GEMMs; residual stream, statistics, attention, logits and the sampling tail stay fp32); "fp32" (default) is the exact path,
+        bit for bit.  Objects that captured the model's launches or sized a workspace before the switch (`GraphSampler`, `new_workspace`)
+        must be rebuilt after it."""
+        modes = {"fp32": 0, "f32": 0, "bf16": 1}
+        if mode not in modes:
+            raise ValueError("gemm precision must be 'fp32' or 'bf16'")
+        self._precision = modes[mode]
+        if self._handle is not None:
+            dev = self._require_hip()
+            with torch.cuda.device(dev):
+                _lib.check(_lib.load().paella_unet_set_precision(self._handle, self._precision, _lib.stream_ptr(dev)))
+        self._ws = None
+        return self
+
+    def get_gemm_precision(self):
+        return "bf16" if self._precision == 1 else "fp32"
 
     def __del__(self):
         h = getattr(self, "_handle", None)
