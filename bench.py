@@ -256,6 +256,7 @@ def main():
     vq = paella_amd.VQModel(**vcfg)
     vq_sd = synth.randomize_(vq, seed=0)
     vq = vq.to(device)
+    vq.set_gemm_precision(a.gemm)
     mk_cond = lambda n, seed: synth.synth_conditioning(n, 0, mcfg["byt5_embd"], mcfg["clip_embd"], seed=seed, device=device)
 
     total = a.batch * world

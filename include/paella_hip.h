@@ -198,7 +198,11 @@ int paella_vqgan_create(const paella_vqgan_config* cfg, paella_vqgan** out);
 void paella_vqgan_destroy(paella_vqgan* v);
 int paella_vqgan_load_tensor(paella_vqgan* v, const char* key, const float* dev_src, const int64_t* shape, int ndim,
                              void* stream);
-int paella_vqgan_finalize(paella_vqgan* v, void* stream); /* synchronises the stream once (reads BN stats / gammas) */
+int paella_vqgan_finalize(paella_vqgan* v, void* stream);
+/* OPT-IN fast mode of ONE VQGAN (outside the fp32 parity contract, as paella_unet_set_precision): mode 1 runs the MLP of every ResBlock whose width is a
+ * multiple of 64 on bf16-operand MFMA with fp32 accumulation (bf16 shadow weights, bf16 LayerNorm output and hidden tensor); everything else stays fp32.
+ * Mode 0 (default) is the exact path.  Size workspaces (paella_vqgan_workspace_bytes) AFTER switching. */
+int paella_vqgan_set_precision(paella_vqgan* v, int mode, void* stream); /* synchronises the stream once (reads BN stats / gammas) */
 /* h, w = latent grid; covers decode and encode of the matching image size */
 size_t paella_vqgan_workspace_bytes(const paella_vqgan* v, int B, int h, int w);
 /* decode_indices (src/vqgan.py:103-107): idx int64 [B,h,w] -> image fp32 NCHW [B,3,f*h,f*w], f = 2^levels */

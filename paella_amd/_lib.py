@@ -71,6 +71,7 @@ SIGNATURES = {
     "paella_vqgan_destroy": (None, [c_void_p]),
     "paella_vqgan_load_tensor": (c_int, [c_void_p, c_char_p, c_void_p, POINTER(c_int64), c_int, c_void_p]),
     "paella_vqgan_finalize": (c_int, [c_void_p, c_void_p]),
+    "paella_vqgan_set_precision": (c_int, [c_void_p, c_int, c_void_p]),
     "paella_vqgan_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int, c_int]),
     "paella_vqgan_decode_indices": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "paella_vqgan_decode": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),

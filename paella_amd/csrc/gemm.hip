@@ -1464,24 +1464,38 @@ static void choose_config_bf16(int M, int N, int K, int apro, size_t slab_cap_by
     const long ktiles = K / 64;
     const double macs = (double)M * N * K;
     const long T256 = tiles_of_cfg(36, M, N), T128 = tiles_of_cfg(10, M, N), T64 = tiles_of_cfg(18, M, N);
-    const bool no_big = (g_bf16_rule.load(std::memory_order_relaxed) & 1) != 0;
+    const int rule = g_bf16_rule.load(std::memory_order_relaxed);
+    const bool no_big = (rule & 1) != 0, no_persist = (rule & 2) != 0;
     int cfg;
     long G;
-    if (!no_big && T256 >= 448) { cfg = 36; G = T256; }
-    else if (T128 >= 1024) { cfg = 10; G = T128; }
-    else if (macs >= 2.5e9) {
-        if (!no_big && T256 >= 32 && apro != 2) { cfg = 36; G = 256; }
-        else if (T128 >= 64) { cfg = 10; G = T128 >= 256 ? T128 : 256; }
-        else { cfg = 18; G = T64 >= 512 ? T64 : 512; }
+    // (profiles/r05_gemm_bf16_tile_sweep.txt; TFLOP/s in isolation, fp32 outputs)
+    if (!no_big && T256 >= 1024) {
+        // BASELINE configs[2]-class launches: 256x128 tiles.  Long K (>= 2560): one tile per workgroup (32768x1280x5120: 950, 131072x640x2560: 800).  Short K: the
+        // epilogue is a large share of a tile, so 256 persistent workgroups walk balanced ranges of >= 4 tiles each and one tile's stores overlap the next one's
+        // operand stream (32768x5120x1280: 819 against 636; 131072x2560x640: 500-515 against 465).  A LayerNorm-consuming launch keeps one tile per workgroup
+        // (its row statistics are derived once per workgroup).
+        cfg = 36;
+        G = (K <= 1280 && apro != 2 && !no_persist) ? ((K <= 640 && T256 >= 4096) ? 512 : 256) : T256;
+    } else if (!no_big && T256 >= 128 && (K >= 2560 || T256 >= 256) && !(K <= 1280 && T64 >= 4096)) {
+        cfg = 36; G = T256;    // 4096x1280x5120: 723 (160 tiles); 4096x3840x1280: 604; 16384x640x2560: 603
+    } else if (T64 >= 4096) {
+        cfg = 18; G = T64;     // 4096x5120x1280: 620 against 563 for 640 tiles of 256x128 (2.5 rounds of the chip)
+    } else if (T64 >= 256 && macs < 1.0e10 && K <= 1280) {
+        cfg = 34; G = tiles_of_cfg(34, M, N);   // 64x64 ring tile: 4096x1280x1280 456, 1024x5120x1280 394, 1024x1280x1280 268
+    } else if (macs >= 2.5e9) {
+        cfg = 10; G = T128 >= 256 ? T128 : 256;  // 1024x1280x5120: 318 on 256 balanced ranges of 128x128 tiles
     } else {
-        cfg = apro == 2 ? 31 : 30;
-        const long resident = ring_resident(cfg, apro);
+        // skinny batch-1 launches: the 4-stage 32x32 ring tile; with the matrix cores 16x faster a launch is its latency chain, and every K split adds a
+        // publish / ticket / combine round trip -- one tile per workgroup from 160 tiles up or for K <= 1280, otherwise split towards ~512 workgroups with
+        // at least 16 K steps (1024 elements) each (128x5120x1280: 12.0 us unsplit against 14.0 on 1280 ranges; 128x1280x5120: 12.4 on 512 against 16.1)
+        cfg = 31;
         const long Tc = tiles_of_cfg(cfg, M, N);
-        const long U = Tc * ktiles;
-        if (apro == 2) G = Tc >= 160 ? Tc : 2 * Tc;
-        else G = U / 5;  // ~5 K steps of 64 per workgroup (the fp32 rule's ~10 steps of 32)
-        if (G < Tc) G = Tc;
-        if (G > resident) G = resident;
+        long S = (512 + Tc / 2) / (Tc > 0 ? Tc : 1);
+        if (S > ktiles / 16) S = ktiles / 16;
+        if (S < 1 || apro == 2) S = 1;
+        G = Tc * S;
+        const long resident = ring_resident(cfg, apro);
+        if (G > resident && S > 1) G = resident;
     }
     const long T = tiles_of_cfg(cfg, M, N);
     const long U = T * ktiles;

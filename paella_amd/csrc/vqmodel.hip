@@ -32,11 +32,19 @@ struct paella_vqgan {
     DevBuf bn_scale, bn_shift;
     bool finalized = false;
     float bn_eps = 1e-5f;
+    // OPT-IN bf16 fast mode of THIS model (paella_vqgan_set_precision; outside the fp32 parity contract): bf16 shadows of the ResBlocks' MLP weights
+    int precision = 0;
+    std::map<std::string, DevBuf16> t16;
 };
 
 static const float* VT(const paella_vqgan* v, const std::string& k) {
     auto it = v->t.find(k);
     return it == v->t.end() ? nullptr : it->second.p;
+}
+static const unsigned short* VT16(const paella_vqgan* v, const std::string& k) {
+    if (v->precision != 1) return nullptr;
+    auto it = v->t16.find(k);
+    return it == v->t16.end() ? nullptr : it->second.p;
 }
 static void vspec(paella_vqgan* v, const std::string& key, Repack kind, std::vector<int64_t> shape) {
     VqSpec s; s.kind = kind; s.shape = std::move(shape);
@@ -135,6 +143,7 @@ extern "C" int paella_vqgan_create(const paella_vqgan_config* cfg, paella_vqgan*
 extern "C" void paella_vqgan_destroy(paella_vqgan* v) {
     if (!v) return;
     for (auto& kv : v->t) if (kv.second.p) (void)hipFree(kv.second.p);
+    for (auto& kv : v->t16) if (kv.second.p) (void)hipFree(kv.second.p);
     for (auto* seq : {&v->enc, &v->dec})
         for (auto& b : *seq)
             for (auto& pw : b.phase_w) if (pw.p) (void)hipFree(pw.p);
@@ -156,6 +165,25 @@ extern "C" int paella_vqgan_load_tensor(paella_vqgan* v, const char* key, const 
     return repack_into(sp.kind, dev_src, sp.shape, v->t[key], (hipStream_t)stream);
 }
 
+
+static int vq_make_shadows(paella_vqgan* v, hipStream_t st) {
+    for (auto* seq : {&v->enc, &v->dec})
+        for (auto& b : *seq) {
+            if (b.op != VQ_RES || (b.c_in % 64)) continue;
+            for (const char* suffix : {".channelwise.0.weight", ".channelwise.2.weight"}) {
+                const std::string k = b.prefix + suffix;
+                auto it = v->t.find(k);
+                if (it == v->t.end() || !it->second.p) continue;
+                DevBuf16& d = v->t16[k];
+                if (d.p && d.n != it->second.n) { (void)hipFree(d.p); d.p = nullptr; }
+                if (!d.p) HIP_CHECK_RET(hipMalloc((void**)&d.p, it->second.n * sizeof(unsigned short)));
+                d.n = it->second.n;
+                RET_IF(launch_f32_to_bf16(it->second.p, d.p, d.n, st));
+            }
+        }
+    HIP_CHECK_RET(hipStreamSynchronize(st));
+    return PAELLA_OK;
+}
 
 extern "C" int paella_vqgan_finalize(paella_vqgan* v, void* stream) {
     if (!v) { paella_set_error("null argument"); return PAELLA_ERR_ARG; }
@@ -203,10 +231,27 @@ extern "C" int paella_vqgan_finalize(paella_vqgan* v, void* stream) {
         }
     HIP_CHECK_RET(hipStreamSynchronize(st));
     v->finalized = true;
+    if (v->precision == 1) RET_IF(vq_make_shadows(v, st));  // (a reload refreshes the shadows)
     return PAELLA_OK;
 }
 
-struct VqBuffers { float *x, *t, *g, *a, *lat, *qe, *splitk; };
+// OPT-IN fast mode of THIS model: mode 1 runs the MLP of every ResBlock whose width is a multiple of 64 on bf16-operand MFMA (bf16 shadow weights, bf16
+// LayerNorm output and hidden tensor; residual stream, depthwise half, the strided convolutions and the image stay fp32).  Mode 0 (default) = the exact path.
+// Size workspaces (paella_vqgan_workspace_bytes) AFTER switching.
+extern "C" int paella_vqgan_set_precision(paella_vqgan* v, int mode, void* stream) {
+    if (!v) { paella_set_error("null argument"); return PAELLA_ERR_ARG; }
+    if (mode != 0 && mode != 1) { paella_set_error("precision mode must be 0 (fp32) or 1 (bf16 operands)"); return PAELLA_ERR_ARG; }
+    v->precision = mode;
+    if (mode == 1 && v->finalized) return vq_make_shadows(v, (hipStream_t)stream);
+    if (mode == 0) {
+        HIP_CHECK_RET(hipDeviceSynchronize());
+        for (auto& kv : v->t16) if (kv.second.p) (void)hipFree(kv.second.p);
+        v->t16.clear();
+    }
+    return PAELLA_OK;
+}
+
+struct VqBuffers { float *x, *t, *g, *a, *lat, *qe, *splitk; unsigned short *t16, *g16; };
 
 // largest activation: at the image-side level the grid is (h*2^(L-1)) x (w*2^(L-1)) with c_levels[0] channels
 static void vq_carve(const paella_vqgan* v, Arena& a, int B, int h, int w, VqBuffers& f) {
@@ -233,6 +278,11 @@ static void vq_carve(const paella_vqgan* v, Arena& a, int B, int h, int w, VqBuf
     f.a = a.take(amax ? amax : 4);
     f.lat = a.take((size_t)B * h * w * v->cfg.c_latent);
     f.qe = a.take((size_t)B * h * w * v->cfg.c_latent);
+    f.t16 = f.g16 = nullptr;
+    if (v->precision == 1) {  // bf16 fast mode: LayerNorm output and hidden tensor of the ResBlock MLPs (after everything else: the fp32 layout does not move)
+        f.t16 = reinterpret_cast<unsigned short*>(a.take(xmax / 2 + 64));
+        f.g16 = reinterpret_cast<unsigned short*>(a.take(2 * xmax + 64));
+    }
 }
 
 extern "C" size_t paella_vqgan_workspace_bytes(const paella_vqgan* v, int B, int h, int w) {
@@ -250,6 +300,24 @@ static int vq_resblock(const paella_vqgan* v, const VqBlock& b, VqBuffers& f, in
     RET_IF(launch_layernorm(f.x, f.t, rows, c, 1e-6f, 1.0f + b.gam[0], b.gam[1], 0, 0, 0, st));
     RET_IF(launch_dwconv_res(f.x, f.t, VT(v, b.prefix + ".depthwise.1.weight"), VT(v, b.prefix + ".depthwise.1.bias"), f.x, B, h, w, c,
                              b.gam[2], st));
+    const unsigned short* const w1_16 = VT16(v, b.prefix + ".channelwise.0.weight");
+    const unsigned short* const w2_16 = VT16(v, b.prefix + ".channelwise.2.weight");
+    if (w1_16 && w2_16 && f.t16 && (c % 64) == 0) {  // opt-in bf16 fast mode: LayerNorm -> bf16 | GEMM1 -> GELU -> bf16 hidden | GEMM2 -> fp32 residual stream
+        RET_IF(launch_layernorm16(f.x, nullptr, f.t16, rows, c, 1e-6f, 1.0f + b.gam[3], b.gam[4], 0, 0, 0, st));
+        GemmArgs g1 = gemm_args(nullptr, c, VT(v, b.prefix + ".channelwise.0.weight"), c, nullptr, 4 * c, (int)rows, 4 * c, c);
+        g1.A16 = f.t16; g1.W16 = w1_16;
+        g1.ep.bias = VT(v, b.prefix + ".channelwise.0.bias");
+        g1.ep.act = ACT_GELU;
+        g1.ep.c16 = f.g16;
+        RET_IF(launch_gemm(g1, f.splitk, kSplitKBudget, st));
+        GemmArgs g2 = gemm_args(nullptr, 4 * c, VT(v, b.prefix + ".channelwise.2.weight"), 4 * c, f.x, c, (int)rows, c, 4 * c);
+        g2.A16 = f.g16; g2.W16 = w2_16;
+        g2.ep.bias = VT(v, b.prefix + ".channelwise.2.bias");
+        g2.ep.alpha = b.gam[5];
+        g2.ep.residual = f.x; g2.ep.ldr = c;
+        RET_IF(launch_gemm(g2, f.splitk, kSplitKBudget, st));
+        return PAELLA_OK;
+    }
     RET_IF(launch_layernorm(f.x, f.t, rows, c, 1e-6f, 1.0f + b.gam[3], b.gam[4], 0, 0, 0, st));
     GemmArgs g1 = gemm_args(f.t, c, VT(v, b.prefix + ".channelwise.0.weight"), c, f.g, 4 * c, (int)rows, 4 * c, c);
     g1.ep.bias = VT(v, b.prefix + ".channelwise.0.bias");

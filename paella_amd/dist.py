@@ -99,7 +99,8 @@ def _pack_seed(seed, device):
     return torch.tensor([int(seed)], dtype=torch.int64).view(torch.float32).to(device)
 
 
-def broadcast_conditioning(input_sets, src=0, device=None, group=None, layout=None, seed=None, with_seed=False, seed_on_device=False, validate=None):
+def broadcast_conditioning(input_sets, src=0, device=None, group=None, layout=None, seed=None, with_seed=False, seed_on_device=False, validate=None,
+                           return_flag=False):
     """Broadcast a list of conditioning dicts (e.g. [model_inputs, unconditional_inputs]) from `src` with ONE
     tensor collective.  Non-source ranks pass None.  Without `layout` the shapes travel first in one small object
     broadcast (which synchronises host and device; a receiver cannot size its buffer otherwise); with `layout` =
@@ -112,7 +113,11 @@ def broadcast_conditioning(input_sets, src=0, device=None, group=None, layout=No
     with a wrong-sized buffer (the other ranks would block forever): the source sends a buffer of the AGREED size whose trailing
     flag word is 0 and whose payload is NaN, then raises ValueError; receivers raise too when validate=True (default on the
     handshake path, which synchronises anyway; on the layout path it costs one host sync, so it defaults to False there and a
-    receiver of a poisoned buffer computes NaN-conditioned output instead of hanging)."""
+    receiver of a poisoned buffer computes NaN-conditioned output instead of hanging).
+    return_flag=True is the form for callers that issue FURTHER collectives (sample_sharded): nothing is raised here, not even on the
+    source, and the result carries (ok_dev, src_bad) at its end -- ok_dev = the flag word as a 1-element fp32 DEVICE tensor (1 = valid,
+    0 = poisoned; consume it on the device, e.g. to poison the outputs with -1, without a host sync), src_bad = the source's host-side
+    knowledge of the mismatch (always False on receivers) -- so that every rank can keep its collective sequence and fail together."""
     rank = dist.get_rank(group)
     meta = [None]
     flat = None
@@ -148,10 +153,12 @@ def broadcast_conditioning(input_sets, src=0, device=None, group=None, layout=No
             raise ValueError("non-source ranks must pass device")
         flat = torch.empty(numel + extra, dtype=torch.float32, device=device)
     dist.broadcast(flat, src=src, group=group)
-    if bad:
-        raise ValueError("conditioning does not match the agreed layout (a poisoned buffer of the agreed size was broadcast so that no rank blocks)")
-    if validate and float(flat[numel + extra - 1].item()) != 1.0:
-        raise ValueError("the source rank's conditioning did not match the agreed layout")
+    ok_dev = flat[numel + extra - 1:numel + extra]
+    if not return_flag:
+        if bad:
+            raise ValueError("conditioning does not match the agreed layout (a poisoned buffer of the agreed size was broadcast so that no rank blocks)")
+        if validate and float(ok_dev.item()) != 1.0:
+            raise ValueError("the source rank's conditioning did not match the agreed layout")
     if with_seed:
         seed_t = flat[numel:numel + 2].clone().view(torch.int64)  # 1-element int64 tensor on the buffer's device
         seed = seed_t if seed_on_device else int(seed_t.item())
@@ -167,7 +174,10 @@ def broadcast_conditioning(input_sets, src=0, device=None, group=None, layout=No
                 n += m
         out.append(_unflatten(flat[off:off + n], d, flat.device))
         off += n
-    return (out, seed) if with_seed else out
+    res = (out, seed) if with_seed else out
+    if return_flag:
+        return (res + (ok_dev, bad)) if with_seed else (res, ok_dev, bad)
+    return res
 
 
 def shard_inputs(inputs, lo, hi):
@@ -215,16 +225,27 @@ def sample_sharded(model, model_inputs, unconditional_inputs, latent_shape, src=
     device = next(model.parameters()).device
     philox = noise == "philox"
     res = broadcast_conditioning([model_inputs, unconditional_inputs] if rank == src else None, src=src, device=device, group=group,
-                                 layout=layout, seed=seed, with_seed=philox, seed_on_device=philox)
-    (cond, uncond), seed_dev = res if philox else (res, None)  # the seed stays on the device: no host sync between the broadcast and the sampler
+                                 layout=layout, seed=seed, with_seed=philox, seed_on_device=philox, return_flag=True)
+    # the seed and the validity flag stay on the device: no host sync between the broadcast and the sampler
+    ((cond, uncond), seed_dev, ok_dev, src_bad) = res if philox else (res[0], None, res[1], res[2])
     B, H, W = latent_shape
     lo, hi = shard_bounds(B, rank, world)
     shard = (lo, B) if philox else None
     local = None
+    # A conditioning that does not match the agreed layout is known on the source's host and reaches the other ranks as the flag word of the
+    # (well-formed, NaN-filled) broadcast.  The failure is COLLECTIVE: nobody raises before the gather, the source contributes -1 tokens without
+    # sampling, every receiver's tokens are replaced by -1 ON THE DEVICE (one select on the flag word, no host sync), and every rank raises after
+    # the gather -- no rank is left waiting in a collective the others never enter.
     if hi > lo:
-        local = sample(model, shard_inputs(cond, lo, hi), (hi - lo, H, W), unconditional_inputs=shard_inputs(uncond, lo, hi),
-                       device=device, noise=noise, seed=0 if philox else seed, seed_dev=seed_dev, shard=shard, **kwargs)
+        if src_bad:
+            local = torch.full((hi - lo, H, W), -1, dtype=torch.int64, device=device)
+        else:
+            local = sample(model, shard_inputs(cond, lo, hi), (hi - lo, H, W), unconditional_inputs=shard_inputs(uncond, lo, hi),
+                           device=device, noise=noise, seed=0 if philox else seed, seed_dev=seed_dev, shard=shard, **kwargs)
+            local = torch.where(ok_dev.to(local.device) == 1.0, local, torch.full_like(local, -1))
     if not gather:
+        if src_bad:
+            raise ValueError("conditioning does not match the agreed layout (a poisoned buffer of the agreed size was broadcast: the other ranks return -1 tokens)")
         return local
     sizes = [shard_bounds(B, r, world) for r in range(world)]
     mx = max(h - l for l, h in sizes)
@@ -233,4 +254,7 @@ def sample_sharded(model, model_inputs, unconditional_inputs, latent_shape, src=
         pad[:hi - lo] = local
     outs = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(outs, pad, group=group)
-    return torch.cat([o[:h - l] for o, (l, h) in zip(outs, sizes)], dim=0)
+    out = torch.cat([o[:h - l] for o, (l, h) in zip(outs, sizes)], dim=0)
+    if src_bad or (layout is not None and out.numel() and int(out.min()) < 0):  # (the gathered tokens are about to be consumed by the host anyway)
+        raise ValueError("the source rank's conditioning did not match the agreed layout: every rank received poisoned (-1) tokens")
+    return out

@@ -96,6 +96,25 @@ class VQModel(nn.Module):
         self._handle = None
         self._loaded_sig = None
         self._ws = None
+        self._precision = 0
+
+    def set_gemm_precision(self, mode):
+        """OPT-IN fast mode of THIS model, outside the fp32 parity contract (include/paella_hip.h: paella_vqgan_set_precision): "bf16" runs the ResBlock
+        MLPs on bf16-operand MFMA with fp32 accumulation; "fp32" (default) is the exact path.  Rebuild objects that sized a workspace / captured
+        launches before the switch (`GraphSampler`)."""
+        modes = {"fp32": 0, "f32": 0, "bf16": 1}
+        if mode not in modes:
+            raise ValueError("gemm precision must be 'fp32' or 'bf16'")
+        self._precision = modes[mode]
+        if self._handle is not None:
+            dev = self._device()
+            with torch.cuda.device(dev):
+                _lib.check(_lib.load().paella_vqgan_set_precision(self._handle, self._precision, _lib.stream_ptr(dev)))
+        self._ws = None
+        return self
+
+    def get_gemm_precision(self):
+        return "bf16" if self._precision == 1 else "fp32"
 
     @torch.no_grad()
     def reset_parameters(self):
@@ -131,6 +150,8 @@ class VQModel(nn.Module):
                 h = ctypes.c_void_p()
                 _lib.check(lib.paella_vqgan_create(ctypes.byref(c), ctypes.byref(h)))
                 self._handle = h
+                if self._precision:
+                    _lib.check(lib.paella_vqgan_set_precision(self._handle, self._precision, _lib.stream_ptr(dev)))
             st = _lib.stream_ptr(dev)
             for key, t in self.state_dict().items():
                 if key.endswith("num_batches_tracked"):

@@ -92,7 +92,7 @@ def _shard_worker(rank, world, port, q):
             pos = torch.arange(shard[0] * H * W, (shard[0] + B) * H * W).view(B, H, W)   # GLOBAL position index
             toks = (pos * 2654435761 + int(seed) % 1000003) % 8191                         # a pure function of (seed, global position)
             rows = torch.arange(shard[0], shard[0] + B)[:, None, None]
-            return (toks + rows * 7 + int(model_inputs["clip"].sum().round())) % model.num_labels
+            return (toks + rows * 7 + int(torch.nan_to_num(model_inputs["clip"]).sum().round())) % model.num_labels  # (a poisoned, NaN-filled conditioning must not raise here: the HIP sampler does not either)
 
         S.sample = fake_sample
         g = torch.Generator().manual_seed(1)
@@ -139,6 +139,22 @@ def _shard_worker(rank, world, port, q):
         calls.clear()
         sample_sharded(_FakeModel(), cond if rank == 0 else None, uncond if rank == 0 else None, (B, H, W), src=0, seed=1234)
         ok = ok and calls[0][1] == 1234
+        # a source-side conditioning that does not match the agreed layout fails COLLECTIVELY: with gather=True every rank leaves the
+        # all_gather and raises; with gather=False the source raises and the receivers hold -1 tokens (poisoned on the device by the flag word)
+        bad_cond = dict(cond, byt5=torch.randn(B, 2, 8, generator=g))   # S_byt5 = 2 against a layout that says 0
+        raised = False
+        try:
+            sample_sharded(_FakeModel(), bad_cond if rank == 0 else None, uncond if rank == 0 else None, (B, H, W), src=0, gather=True, layout=lay)
+        except ValueError:
+            raised = True
+        ok = ok and raised
+        raised, toks = False, None
+        try:
+            toks = sample_sharded(_FakeModel(), bad_cond if rank == 0 else None, uncond if rank == 0 else None, (B, H, W), src=0, gather=False, layout=lay)
+        except ValueError:
+            raised = True
+        ok = ok and (raised if rank == 0 else (not raised and bool((toks == -1).all())))
+        dist.barrier()  # nobody is stuck in a collective
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()

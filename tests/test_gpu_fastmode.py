@@ -201,3 +201,23 @@ def test_bf16_sampling_fused_equals_unfused_and_runs_end_to_end(built_lib):
     m.set_gemm_precision("fp32")
     exact = paella_amd.sample(m, cs, (2, 16, 16), **kw)
     print("bf16 vs fp32 sampled tokens that differ after 4 steps: %d of %d" % (int((exact != toks).sum()), toks.numel()))
+
+
+def test_bf16_vqgan_decode_deviation_and_restore(built_lib):
+    """The VQGAN's opt-in mode (ResBlock MLPs on bf16 operands): small deviation on the image, per model, exact path restored bit for bit."""
+    vc = dict(levels=3, bottleneck_blocks=3, c_hidden=256, c_latent=4, codebook_size=512, scale_factor=0.3764)  # widths 256 / 128 / 64: every ResBlock eligible
+    vq = paella_amd.VQModel(**vc)
+    weights_for(vq, 2)
+    vq = vq.to(DEV)
+    g = torch.Generator().manual_seed(11)
+    idx = torch.randint(0, vc["codebook_size"], (2, 8, 8), generator=g).to(DEV)
+    exact = vq.decode_indices(idx).clone()
+    vq.set_gemm_precision("bf16")
+    fast = vq.decode_indices(idx).clone()
+    vq.set_gemm_precision("fp32")
+    again = vq.decode_indices(idx)
+    diff, scale = (fast - exact).abs().max().item(), exact.abs().max().item()
+    print("VQGAN bf16 fast mode: max|image diff| %.3e on images of max |value| %.3f" % (diff, scale))
+    assert torch.isfinite(fast).all() and not torch.equal(fast, exact)
+    assert diff <= 0.05 * max(1.0, scale)
+    assert torch.equal(again, exact)
