@@ -103,9 +103,11 @@ TEST_HOOKS = {
     "paella_test_gemm_dma": (c_int, [c_int]),
     "paella_test_gemm_raster": (c_int, [c_int]),
     "paella_test_gemm_ring": (c_int, [c_int]),
+    "paella_test_ring_resident": (ctypes.c_long, [c_int, c_int]),
     "paella_test_gemm_big_stagger": (c_int, [c_int]),
     "paella_test_grn_fuse": (c_int, [c_int]),
     "paella_test_ln_fold_ratio": (c_int, [c_float]),
+    "paella_test_ln_guard_counter": (c_int, [c_void_p]),
     "paella_test_mlp_grn_fused": (c_int, [c_void_p] * 10 + [c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "paella_test_gemm_tail_tile": (c_int, [c_int]),
     "paella_test_tail_scores": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, c_float, c_float, c_uint64, c_uint64, c_int64, c_void_p, c_void_p]),

@@ -14,8 +14,14 @@ def source_files():
     return [os.path.normpath(os.path.join(CSRC, f)) for f in SOURCES + HEADERS]
 
 
+# the compile configuration is part of what a library was "built from": changing a flag or the target must not reuse stale objects
+ARCH = "gfx950"
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
 def source_stamp():
     h = hashlib.sha256()
+    h.update(" ".join(FLAGS).encode())
     for path in source_files():
         h.update(os.path.basename(path).encode())
         with open(path, "rb") as f:

@@ -379,7 +379,11 @@ int launch_attention(const AttnArgs& a, hipStream_t st) {
         else hipLaunchKernelGGL((attention_kernel<n, false>), grid, dim3(256), 0, st, a);                  \
         break;
     switch (a.D / 16) {
-        ATT_CASE(1) ATT_CASE(2) ATT_CASE(3) ATT_CASE(4) ATT_CASE(5) ATT_CASE(6) ATT_CASE(7) ATT_CASE(8)
+        case 1:  // head_dim 16 (toy models): the LDS-staged instantiation spills; the register-fed kernel serves large query counts there
+            if (ksplit) hipLaunchKernelGGL((attention_kernel<1, true>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((attention_kernel<1, false>), grid, dim3(256), 0, st, a);
+            break;
+        ATT_CASE(2) ATT_CASE(3) ATT_CASE(4) ATT_CASE(5) ATT_CASE(6) ATT_CASE(7) ATT_CASE(8)
     }
 #undef ATT_CASE
     switch (0) {

@@ -153,6 +153,7 @@ struct GemmArgs {
     const float* ln_row;       // optional [M, 4]: the rows' FINISHED statistics (mean, rstd, mean - (float)mean, |mean| * rstd) from launch_ln_rowstat_finalize -- set by the launcher in the throughput regime
     float ln_fold_ratio;       // 16-row blocks with |mean| * rstd above this normalise their operand fragments instead of using the fold (set by launch_gemm_cfg)
     const float* ln_wsum;      // [N]: sum_k W[n][k] -- the LayerNorm is folded into the epilogue as rstd * (acc - mean * wsum[n]) (gemm.hip: ln_row_stats)
+    unsigned* ln_guard_count;  // test hook (null in the product): += 1 per wave whose rows took the operand-side LayerNorm instead of the fold (paella_test_ln_guard_counter)
     Epilogue ep;
     FusedTail ft;              // used by launch_gemm_tail only
     ConvGather cv;             // cv.enabled: A is an NHWC image gathered on the fly (lda unused, K == ntaps * C)

@@ -105,7 +105,8 @@ int launch_dwconv_ln(const float* x, const float* skip, const float* w, const fl
                      int W, int C, float eps, hipStream_t st, unsigned short* y16) {
     const int64_t total = (int64_t)B * H * W;
     if (total <= 0) return PAELLA_OK;
-    if ((C & 3) || (skip && (C & 7)) || C > 8192) { paella_set_error("dwconv_ln: bad channel count %d", C); return PAELLA_ERR_ARG; }
+    // (the skip variant holds two activation loads per tap: its 8-slot instantiation spilled 1.9 KB per lane to scratch -- it stops at 4096 channels, 3x the widest released level)
+    if ((C & 3) || (skip && (C & 7)) || C > 8192 || (skip && C > 4096)) { paella_set_error("dwconv_ln: bad channel count %d", C); return PAELLA_ERR_ARG; }
     if (total > 0x7fffffff) { paella_set_error("dwconv_ln: too many positions"); return PAELLA_ERR_ARG; }
     const int nv = (C / 4 + 255) / 256;
     const dim3 grid((unsigned)total), block(256);
@@ -118,7 +119,7 @@ int launch_dwconv_ln(const float* x, const float* skip, const float* w, const fl
     if (nv <= 1) DW_LAUNCH(1);
     else if (nv <= 2) DW_LAUNCH(2);
     else if (nv <= 4) DW_LAUNCH(4);
-    else DW_LAUNCH(8);
+    else hipLaunchKernelGGL((dwconv_ln_block_kernel<8, false>), grid, block, 0, st, x, skip, w, bias, y, y16, H, W, C, eps, dW, dH);
 #undef DW_LAUNCH
     LAUNCH_CHECK_RET();
     return PAELLA_OK;

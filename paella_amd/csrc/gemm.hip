@@ -310,6 +310,7 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (WM * WN == 8 ? 1 : TM * T
                     ln_dir[i] = !BF && __builtin_amdgcn_ballot_w64(v[3] > g.ln_fold_ratio) != 0;
                     ln_any = ln_any || ln_dir[i];
                 }
+                if (g.ln_guard_count && ln_any && lane_k == 0) atomicAdd(g.ln_guard_count, 1u);  // test hook only (null in the product)
                 return;
             }
             const int nch = g.ln_nblk >> 1;
@@ -342,6 +343,7 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (WM * WN == 8 ? 1 : TM * T
                 ln_dir[i] = !BF && __builtin_amdgcn_ballot_w64(fabsf(fr_mu[i]) * fr_rs[i] > g.ln_fold_ratio) != 0;  // wave-uniform, a function of the block's 16 rows only
                 ln_any = ln_any || ln_dir[i];
             }
+            if (g.ln_guard_count && ln_any && lane_k == 0) atomicAdd(g.ln_guard_count, 1u);  // test hook only (null in the product)
         }
     };
     // operand-side LayerNorm of an A fragment (row block i, 4 consecutive k from kbase) -- only for blocks flagged by ln_row_stats; zero past K like the staged K tail
@@ -1384,6 +1386,9 @@ static long ring_resident(int cfg, int apro) {
     }
 }
 
+// test hook (tests/test_kernel_resources.py): the table above, so that a CPU test can hold it against the occupancy the compiler actually produced
+extern "C" long paella_test_ring_resident(int cfg, int apro) { return (cfg >= 30 && cfg <= 35) ? ring_resident(cfg, apro) : -1; }
+
 static void choose_config(int M, int N, int K, int apro, bool ring_allowed, int force_ring, size_t slab_cap_bytes, int* cfg_out, unsigned* G_out) {
     // one consistent value per decision; force_ring: the caller needs THIS ring tile in the skinny class (its epilogue finishes GRN per tile)
     const int g_gemm_ring = ::g_gemm_ring.load(std::memory_order_relaxed) ? (force_ring > 0 ? force_ring : ::g_gemm_ring.load(std::memory_order_relaxed)) : 0;
@@ -1553,10 +1558,14 @@ static int prof_bracket(const GemmArgs& g, hipStream_t st, bool stores_c, F&& la
 // threshold of the LayerNorm fold (gemm_device.h: kLnFoldMaxRatio); the test hook moves it to measure the fold's error curve (inf = always fold, 0 = never)
 static std::atomic<float> g_ln_fold_ratio{kLnFoldMaxRatio};
 extern "C" int paella_test_ln_fold_ratio(float ratio) { g_ln_fold_ratio = ratio; return PAELLA_OK; }
+// test hook: a device word that counts the waves of LayerNorm-consuming GEMM launches whose rows took the operand-side path (null = off, the default)
+static std::atomic<unsigned*> g_ln_guard_count{nullptr};
+extern "C" int paella_test_ln_guard_counter(unsigned* dev_word) { g_ln_guard_count = dev_word; return PAELLA_OK; }
 
 int launch_gemm_cfg(const GemmArgs& g_in, int cfg, int splitk, void* ws, size_t ws_bytes, hipStream_t st) {
     GemmArgs g = g_in;
     g.ln_fold_ratio = g_ln_fold_ratio.load(std::memory_order_relaxed);
+    g.ln_guard_count = g_ln_guard_count.load(std::memory_order_relaxed);
     g.a_rps_div = fast_div_of((unsigned)(g.a_rows_per_sample > 0 ? g.a_rows_per_sample : 1));
     g.ep.rps_div = fast_div_of((unsigned)(g.ep.rows_per_sample > 0 ? g.ep.rows_per_sample : 1));
     return prof_bracket(g, st, true, [&]() { return launch_gemm_cfg_impl(g, cfg, splitk, ws, ws_bytes, st); });

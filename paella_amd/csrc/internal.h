@@ -51,7 +51,7 @@ int repack_into(Repack kind, const float* src, const std::vector<int64_t>& shape
 static inline GemmArgs gemm_args(const float* A, int lda, const float* Wt, int ldw, float* C, int ldc, int M, int N, int K) {
     GemmArgs g;
     g.A = A; g.lda = lda; g.W = Wt; g.ldw = ldw; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
-    g.a_scale = nullptr; g.a_shift = nullptr; g.a_rows_per_sample = 1; g.a_rps_div.mul = 0; g.a_rps_div.shr = 0; g.a_rps_div.pass = 0xffffffffu; g.grn_gx = nullptr; g.grn_gamma = nullptr; g.grn_part = nullptr; g.grn_np = 0; g.force_ring_cfg = 0; g.ln_stats = nullptr; g.ln_nblk = 0; g.ln_eps = 1e-6f; g.ln_wsum = nullptr; g.ln_row = nullptr; g.ln_fold_ratio = 4.0f;
+    g.a_scale = nullptr; g.a_shift = nullptr; g.a_rows_per_sample = 1; g.a_rps_div.mul = 0; g.a_rps_div.shr = 0; g.a_rps_div.pass = 0xffffffffu; g.grn_gx = nullptr; g.grn_gamma = nullptr; g.grn_part = nullptr; g.grn_np = 0; g.force_ring_cfg = 0; g.ln_stats = nullptr; g.ln_nblk = 0; g.ln_eps = 1e-6f; g.ln_wsum = nullptr; g.ln_row = nullptr; g.ln_fold_ratio = 4.0f; g.ln_guard_count = nullptr;
     g.ep = make_epilogue();
     g.ft.temperature = 1.f; g.ft.mode = 0; g.ft.seed = 0; g.ft.seed_ptr = nullptr; g.ft.offset = 0; g.ft.row_offset = 0; g.ft.row_offset_ptr = nullptr;
     g.ft.part_score = nullptr; g.ft.part_idx = nullptr;

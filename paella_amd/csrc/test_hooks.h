@@ -32,6 +32,8 @@ int paella_test_mlp_grn_fused(const float* h, const float* W1, const float* b1, 
 int paella_test_gemm_dma(int on);
 /* the LDS-DMA ring tile (config id 30..35) the launch heuristic uses for the skinny batch-1 shapes; 0 = the register-staged / 1-deep kernels (A/B) */
 int paella_test_gemm_ring(int cfg);
+/* the launch heuristic's table of resident workgroups (whole chip) of ring tile cfg (30..35) with operand prologue class apro (0 none, 1 GRN, 2 LayerNorm); -1 otherwise */
+long paella_test_ring_resident(int cfg, int apro);
 /* tile of the fused head GEMM + sampling tail: 9 = 128x128, 14 = 128x64 on 8 waves (several workgroups per CU), 18 = 64x64 direct-to-LDS (four workgroups per CU; default) */
 int paella_test_gemm_tail_tile(int cfg);
 /* tile rows per rasterisation group of the GEMM (default 8); 0 = plain m-fastest tile order (A/B) */
@@ -42,6 +44,9 @@ int paella_test_gemm_big_stagger(int mode);
 /* |mean| / std above which a 16-row block of a LayerNorm-consuming GEMM normalises its operand fragments instead of folding the LayerNorm into the
  * epilogue (default 4; inf = always fold, 0 = never): measures the fold's error curve (tests/test_gpu_ops.py, profiles/r04_ln_fold_error_curve.txt) */
 int paella_test_ln_fold_ratio(float ratio);
+/* dev_word != NULL: every LayerNorm-consuming GEMM launch adds to *dev_word the number of its waves whose 16-row blocks took the operand-side LayerNorm (the
+ * guard tripped); NULL (default) = off.  Lets a whole-network test assert that the guard really ran inside the model (tests/test_gpu_unet.py) */
+int paella_test_ln_guard_counter(unsigned* dev_word);
 /* 0 = GlobalResponseNorm always through the grn_from_partials finalize launch (A/B of the in-GEMM statistics of the batch-1 path); 1 = default */
 int paella_test_grn_fuse(int on);
 /* Measurement hook (bench.py roofline line): when enabled, EVERY dense-contraction launch (the head GEMM with the fused sampling tail included)
