@@ -201,6 +201,7 @@ int launch_layernorm16(const float* x, float* y, unsigned short* y16, int64_t ro
                        int s2d, int H, int W, hipStream_t stream);
 // bf16 helpers of the opt-in fast mode (elementwise.hip): GRN apply in place on the bf16 hidden tensor, weight shadow copies, row sums of a bf16 matrix
 int launch_grn_apply16(unsigned short* h, const float* scale, const float* shift, int64_t rows, int rows_per_sample, int C, hipStream_t stream);
+int launch_grn_partials_apply16(const float* part, const float* gamma, const float* shift, float* scale, unsigned short* h, int B, int rows_per_sample, int C, hipStream_t stream);
 int launch_f32_to_bf16(const float* src, unsigned short* dst, size_t n, hipStream_t stream);
 int launch_rowsum_bf16(const unsigned short* W, float* out, int N, int K, hipStream_t stream);
 

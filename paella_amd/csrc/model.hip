@@ -737,8 +737,7 @@ static int run_mlp_block(FwdCtx& cx, const Block& b, float* x, const float* skip
         g1.ep.c16 = cx.f.g16;
         g1.ep.sumsq_out = cx.f.grn_gx;
         RET_IF(launch_gemm(g1, cx.f.splitk, kSplitKBudget, cx.st));
-        RET_IF(launch_grn_from_partials(cx.f.grn_gx, T(m, b.prefix + ".channelwise.2.gamma"), cx.f.grn_scale, cx.B, rps / 16, 4 * ch, cx.st));
-        RET_IF(launch_grn_apply16(cx.f.g16, cx.f.grn_scale, T(m, b.prefix + ".channelwise.2.beta"), rows, rps, 4 * ch, cx.st));
+        RET_IF(launch_grn_partials_apply16(cx.f.grn_gx, T(m, b.prefix + ".channelwise.2.gamma"), T(m, b.prefix + ".channelwise.2.beta"), cx.f.grn_scale, cx.f.g16, cx.B, rps, 4 * ch, cx.st));
         GemmArgs g2 = gemm_args(nullptr, 4 * ch, T(m, b.prefix + ".channelwise.4.weight"), 4 * ch, x, ch, (int)rows, ch, 4 * ch);
         g2.A16 = cx.f.g16; g2.W16 = w2_16;
         g2.ep.bias = T(m, b.prefix + ".channelwise.4.bias");
