@@ -564,15 +564,18 @@ int launch_grn_apply16(unsigned short* h, const float* scale, const float* shift
 }
 
 // Batch-1 regime of the same: statistics finalize (grn_from_partials_kernel) AND apply in ONE launch -- between the two MLP GEMMs of every block a launch
-// costs ~4-5 us whatever it does.  grid (C / 256, B): every workgroup re-derives the sample's channel mean of Gx from the producer's per-16-row partials
-// (groups x C floats, L2-resident, fixed order -> every workgroup gets the same bits), computes the scale of its own 256 columns and applies it to all rows
-// of the sample.  Only for small launches (the redundant partial reads grow with the workgroup count); larger ones take the two kernels.
+// costs ~4-5 us whatever it does.  grid (C / 256, B, rows per sample / 16): every workgroup re-derives the sample's channel mean of Gx from the producer's
+// per-16-row partials (groups x C floats, L2-resident, fixed order -> every workgroup gets the same bits), computes the scale of its own 256 columns and applies
+// it to its 16 rows (two rows per thread, both loads in flight).  Only for small launches (the redundant partial reads grow with the workgroup count).
 __global__ __launch_bounds__(256) void grn_finalize_apply16_kernel(const float* __restrict__ part, const float* __restrict__ gamma, const float* __restrict__ shift,
                                                                    unsigned short* __restrict__ h, int groups, int C, int rows_per_sample) {
     __shared__ float red[4];
     const int b = blockIdx.y, t = threadIdx.x;
     const int C4 = C >> 2;
     const float* p = part + (size_t)b * groups * C;
+    const int c = blockIdx.x * 256 + (t & 31) * 8;  // this thread's 8 columns
+    unsigned short* hb = h + ((size_t)b * rows_per_sample + blockIdx.z * 16 + (t >> 5)) * C + c;
+    const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(hb), v1 = *reinterpret_cast<const bf16x8*>(hb + (size_t)8 * C);  // (issued first: they fly under the statistics)
     float s = 0.f;
     for (int c4 = t; c4 < C4; c4 += 256) {
         f32x4 q = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -583,28 +586,28 @@ __global__ __launch_bounds__(256) void grn_finalize_apply16_kernel(const float* 
     if ((t & 63) == 0) red[t >> 6] = s;
     __syncthreads();
     const float denom = ((red[0] + red[1]) + (red[2] + red[3])) / (float)C + 1e-6f;
-    const int c = blockIdx.x * 256 + (t & 31) * 8;  // this thread's 8 columns
     f32x4 q0 = f32x4{0.f, 0.f, 0.f, 0.f}, q1 = q0;
     for (int g = 0; g < groups; ++g) { q0 += ld4(p + (size_t)g * C + c); q1 += ld4(p + (size_t)g * C + c + 4); }
     const f32x4 g0 = ld4(gamma + c), g1 = ld4(gamma + c + 4), t0 = ld4(shift + c), t1 = ld4(shift + c + 4);
     f32x4 s0, s1;
 #pragma unroll
     for (int e = 0; e < 4; ++e) { s0[e] = 1.0f + g0[e] * (sqrtf(q0[e]) / denom); s1[e] = 1.0f + g1[e] * (sqrtf(q1[e]) / denom); }
-    unsigned short* hb = h + (size_t)b * rows_per_sample * C + c;
-    for (int row = t >> 5; row < rows_per_sample; row += 8) {
-        const f32x8 f = __builtin_convertvector(*reinterpret_cast<const bf16x8*>(hb + (size_t)row * C), f32x8);
-        f32x8 o;
+    const f32x8 f0 = __builtin_convertvector(v0, f32x8), f1 = __builtin_convertvector(v1, f32x8);
+    f32x8 o0, o1;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { o[e] = f[e] * s0[e] + t0[e]; o[4 + e] = f[4 + e] * s1[e] + t1[e]; }
-        *reinterpret_cast<bf16x8*>(hb + (size_t)row * C) = __builtin_convertvector(o, bf16x8);
+    for (int e = 0; e < 4; ++e) {
+        o0[e] = f0[e] * s0[e] + t0[e]; o0[4 + e] = f0[4 + e] * s1[e] + t1[e];
+        o1[e] = f1[e] * s0[e] + t0[e]; o1[4 + e] = f1[4 + e] * s1[e] + t1[e];
     }
+    *reinterpret_cast<bf16x8*>(hb) = __builtin_convertvector(o0, bf16x8);
+    *reinterpret_cast<bf16x8*>(hb + (size_t)8 * C) = __builtin_convertvector(o1, bf16x8);
 }
 // GlobalResponseNorm of the bf16 fast mode from the producing GEMM's per-16-row partials: scale (kept in `scale` for the two-kernel form) + apply in place
 int launch_grn_partials_apply16(const float* part, const float* gamma, const float* shift, float* scale, unsigned short* h, int B, int rows_per_sample, int C, hipStream_t st) {
     if (B <= 0) return PAELLA_OK;
     if ((rows_per_sample & 15) || (C & 7)) { paella_set_error("grn_apply16: rows per sample %% 16 != 0 or C %% 8 != 0"); return PAELLA_ERR_ARG; }
     if ((C & 255) == 0 && (int64_t)B * rows_per_sample <= 2048) {
-        hipLaunchKernelGGL(grn_finalize_apply16_kernel, dim3(C / 256, B), dim3(256), 0, st, part, gamma, shift, h, rows_per_sample / 16, C, rows_per_sample);
+        hipLaunchKernelGGL(grn_finalize_apply16_kernel, dim3(C / 256, B, rows_per_sample / 16), dim3(256), 0, st, part, gamma, shift, h, rows_per_sample / 16, C, rows_per_sample);
         LAUNCH_CHECK_RET();
         return PAELLA_OK;
     }

@@ -2,6 +2,22 @@
 #pragma once
 #include "common.h"
 
+// Sum over the 16 lanes of a DPP row (the 16 rows r16 of a fragment block), every lane receiving the total: the xor butterfly 1, 2, 4, 8 -- bit for bit, because after
+// the quad steps all lanes of a quad hold the same value, so the mirror partners (7 - i, 15 - i) carry exactly what lanes i ^ 4, i ^ 8 do -- as four v_add_f32_dpp
+// instead of four ds_bpermute_b32 round trips through the LDS pipe (__shfl_xor compiles to ds_bpermute on gfx950; the GRN statistics of an MLP's first GEMM need 16
+// of these reductions per 16x16 accumulator block, 256 per lane and 256x128 tile).
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_mov<0xB1>(v);   // quad_perm [1, 0, 3, 2]  == xor 1
+    v += dpp_mov<0x4E>(v);   // quad_perm [2, 3, 0, 1]  == xor 2
+    v += dpp_mov<0x141>(v);  // row_half_mirror         == xor 4 (quads already uniform)
+    v += dpp_mov<0x140>(v);  // row_mirror              == xor 8 (halves already uniform)
+    return v;
+}
+
 __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
