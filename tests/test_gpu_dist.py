@@ -38,6 +38,7 @@ def test_rccl_shard_path_equals_unsharded():
     print(json.dumps(out))
     assert out["collective_backend"] == "nccl (RCCL)" and out["world_size"] == n
     assert out["sample_sharded_equals_unsharded_rows"] and out["graph_sampler_shard_equals_unsharded_rows"]
+    assert out["mismatched_layout_raises_on_every_rank_after_the_gather"]
 
 
 def test_bench_runs_through_rccl_at_the_world_size_of_the_box():
@@ -47,3 +48,8 @@ def test_bench_runs_through_rccl_at_the_world_size_of_the_box():
     print(json.dumps({k: out[k] for k in ("value", "n_gpus", "ms_per_step", "config")}))
     assert out["config"]["collective_backend"] == "nccl (RCCL)" and out["config"]["world_size_observed"] == n and out["n_gpus"] == n
     assert out["value"] > 0 and out["scaling"] == "weak"
+    # attribution of a step, so that a sub-linear point of a scaling run can be explained from the record alone: wall time per rank (min / max over ranks),
+    # event-timed conditioning broadcast + shard slicing, event-timed sampler
+    c = out["config"]
+    assert set(c["per_rank_ms"]) == {"min", "max"} and 0 < c["per_rank_ms"]["min"] <= c["per_rank_ms"]["max"] <= out["ms_per_step"] * 1.001
+    assert c["broadcast_ms"] > 0 and c["graph_replay_ms"] > 0 and c["broadcast_ms"] + c["graph_replay_ms"] <= out["ms_per_step"] * 1.05

@@ -47,12 +47,20 @@ def main():
     gs = paella_amd.GraphSampler(m, shard_inputs(c_b, lo, hi), shard_inputs(u_b, lo, hi), (hi - lo, H, H), device=dev, **kw)
     out = gs(shard_inputs(c_b, lo, hi), shard_inputs(u_b, lo, hi), seed=int(seed_t.item()), shard=(lo, total)).clone()
     ok_b = bool(torch.equal(out, full[lo:hi]))
-    flags = torch.tensor([int(ok_a), int(ok_b)], device=dev)
+    # (c) a source-side conditioning that does not match the agreed layout fails on EVERY rank after the gather (nobody hangs in a collective)
+    bad = dict(cond, byt5=torch.randn(total, S + 1, TINY["byt5_embd"], device=dev))
+    ok_c = False
+    try:
+        sample_sharded(m, bad if rank == 0 else None, uncond if rank == 0 else None, (total, H, H), src=0, layout=lay, gather=True, seed=77 if rank == 0 else None, **kw)
+    except ValueError:
+        ok_c = True
+    flags = torch.tensor([int(ok_a), int(ok_b), int(ok_c)], device=dev)
     dist.all_reduce(flags, op=dist.ReduceOp.MIN)
     if rank == 0:
         print(json.dumps({"check": "rccl_shard_path", "collective_backend": dist.get_backend() + " (RCCL)", "world_size": dist.get_world_size(),
                           "device": torch.cuda.get_device_name(dev), "images_total": total, "collectives_per_request": 1,
-                          "sample_sharded_equals_unsharded_rows": bool(flags[0].item()), "graph_sampler_shard_equals_unsharded_rows": bool(flags[1].item())}), flush=True)
+                          "sample_sharded_equals_unsharded_rows": bool(flags[0].item()), "graph_sampler_shard_equals_unsharded_rows": bool(flags[1].item()),
+                          "mismatched_layout_raises_on_every_rank_after_the_gather": bool(flags[2].item())}), flush=True)
     dist.destroy_process_group()
     sys.exit(0 if bool(flags.min().item()) else 1)
 
