@@ -200,13 +200,31 @@ def cpu_baseline(model_cfg, vq_cfg, grid, sample_steps, unet_sd, vq_sd, cond, un
                       "(best of a one-step sweep, seconds per step by thread count: %s; host has %d)" % (sample_steps, dt, best, json.dumps(sweep), all_threads)}
 
 
-def gemm_roofline(lib, run_once, device, model, batch, grid, sample_steps, gemm, with_traffic):
+def gemm_roofline(lib, run_once, device, model, batch, grid, sample_steps, gemm, with_traffic, with_latency_model=False):
     """Roofline of the dominant kernel family (fp32 MFMA GEMM): one extra identical pass with every GEMM launch bracketed by HIP
     events on its stream (eager launches; the timed region runs without the events)."""
     import torch
     lib.paella_prof_enable(1)
     run_once()
     torch.cuda.synchronize(device)
+    latency_model = None
+    if with_latency_model:  # per-launch records BEFORE collect() resets them: least-squares fit of t = fixed + flops / rate over the image's GEMM launches
+        import numpy as np
+        cap = 1 << 16
+        us = np.zeros(cap, dtype=np.float32)
+        shp = np.zeros(cap * 5, dtype=np.int32)
+        k = int(lib.paella_prof_detail(us.ctypes.data_as(ctypes.c_void_p), shp.ctypes.data_as(ctypes.c_void_p), cap))
+        if k > 8:
+            sh = shp[:k * 5].reshape(k, 5).astype(np.float64)
+            fl_i, t_i = 2.0 * sh[:, 0] * sh[:, 1] * sh[:, 2], us[:k].astype(np.float64)
+            A = np.stack([np.ones(k), fl_i], axis=1)
+            (c0, c1), *_ = np.linalg.lstsq(A, t_i, rcond=None)
+            resid = t_i - A @ np.array([c0, c1])
+            latency_model = {"form": "launch_us = fixed_us + flops / kloop_tflops, least squares over the GEMM launches of one image (event-bracketed eager pass: the brackets add "
+                                     "~3.5 us per launch to fixed_us; rocprofv3 traces of the same launches: profiles/)",
+                             "launches": k, "fixed_us": round(float(c0), 2), "kloop_tflops": round(1e-6 / float(c1), 1) if c1 > 0 else None,
+                             "rms_residual_us": round(float(np.sqrt((resid ** 2).mean())), 2), "sum_fixed_ms": round(float(c0) * k / 1e3, 3),
+                             "sum_kloop_ms": round(float((fl_i * c1).sum()) / 1e3, 3)}
     ms, fl, by, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
     lib.paella_prof_collect(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by), ctypes.byref(n))
     lib.paella_prof_enable(0)
@@ -231,7 +249,8 @@ def gemm_roofline(lib, run_once, device, model, batch, grid, sample_steps, gemm,
             "launches_per_step": int(n.value), "avg_launch_us": round(ms.value * 1e3 / max(n.value, 1), 2),
             "gemm_ms_per_step": round(ms.value, 3), "executed_gflop_per_step": round(fl.value / 1e9, 1),
             "algorithmic_gbytes_per_step": round(by.value / 1e9, 2),
-            "hbm_equiv_gbs": round(by.value / (ms.value * 1e-3) / 1e9, 1) if ms.value > 0 else 0.0}
+            "hbm_equiv_gbs": round(by.value / (ms.value * 1e-3) / 1e9, 1) if ms.value > 0 else 0.0,
+            "latency_model": latency_model}
 
 
 def main():
@@ -356,7 +375,7 @@ def main():
     roof = None
     if rank == 0:
         c0, u0 = (cond_all, uncond_all) if not distributed else (shard_inputs(cond_all, lo, hi), shard_inputs(uncond_all, lo, hi))
-        roof = gemm_roofline(lib, lambda: eager_fn(c0, u0), device, a.model, a.batch, a.grid, a.sample_steps, a.gemm, True)
+        roof = gemm_roofline(lib, lambda: eager_fn(c0, u0), device, a.model, a.batch, a.grid, a.sample_steps, a.gemm, True, with_latency_model=(a.batch == 1))
     if distributed:
         dist.barrier()
 
