@@ -86,6 +86,9 @@ def parse():
     ap.add_argument("--hook", action="append", default=[], metavar="NAME=INT",
                     help="A/B only: call the library's test hook paella_test_NAME(INT) before building the model (paella_amd/csrc/test_hooks.h); "
                          "recorded in the output line as `test_hooks` -- a line with hooks set is not the product configuration")
+    ap.add_argument("--s-byt5", type=int, default=0, help="ByT5 conditioning rows (0 = CLIP-text only, the headline; 256 for the configs[3] / configs[4] shares)")
+    ap.add_argument("--clip-image", type=int, default=0, help="number of CLIP image embeddings in the conditioning (configs[3] / configs[4]: 1)")
+    ap.add_argument("--inpaint", action="store_true", help="the configs[4] path: VQGAN encode -> masked renoise -> sample(init_x, t_start 0.5) -> decode (eager)")
     ap.add_argument("--force-dist", action="store_true", help="take the torch.distributed (RCCL) path even at world size 1 (launch under torchrun)")
     return ap.parse_args()
 
@@ -300,7 +303,7 @@ def main():
     model, vq, unet_sd, vq_sd = get_model(a.model)
     model.set_gemm_precision(a.gemm)  # per-model switch; "fp32" (default) = the exact path
     vq.set_gemm_precision(a.gemm)
-    mk_cond = lambda n, seed, name=a.model, S_byt5=0, n_ci=0: synth.synth_conditioning(n, S_byt5, MODELS[name]["byt5_embd"], MODELS[name]["clip_embd"], seed=seed,
+    mk_cond = lambda n, seed, name=a.model, S_byt5=a.s_byt5, n_ci=a.clip_image: synth.synth_conditioning(n, S_byt5, MODELS[name]["byt5_embd"], MODELS[name]["clip_embd"], seed=seed,
                                                                                         n_clip_image=n_ci, device=device)
 
     total = a.batch * world
@@ -314,7 +317,7 @@ def main():
     layout = conditioning_layout([tmpl, tmpl]) if distributed else None
     use_graph = not a.no_graph and a.noise == "philox"
 
-    def make_runner(batch, grid, sample_steps, seed_base, name=None, S_byt5=0, n_ci=0, inpaint=False, graph=True):
+    def make_runner(batch, grid, sample_steps, seed_base, name=None, S_byt5=a.s_byt5, n_ci=a.clip_image, inpaint=a.inpaint, graph=True):
         """(step function replaying the captured graph or launching eagerly, eager step function for the profiling pass)"""
         name = name or a.model
         mdl, vqm = get_model(name)[:2]

@@ -3,7 +3,7 @@
 # Output: gpurun_out/<tag>_profiles/ -- kernel-trace summaries (batch 1, batch 32, BASELINE configs[2]), the HBM traffic files
 # bench.py reads (tools/pmc_traffic.py; stamped with the kernel-source hash), matrix-core busy counters.  Counters are collected
 # in passes of their own with --kernel-trace only (MI355X_MICROARCH.md, HBM / rocprofv3 section).
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/${TAG}_profiles
 mkdir -p $O
@@ -23,8 +23,15 @@ trace() {  # name, images, command...
 trace bench_b1_570m 6 $W_B1 --steps 4 --warmup 1 $COMMON
 trace bench_b32_570m 96 $W_B32 --steps 1 --warmup 1 $COMMON
 trace config3_b64_64x64 192 $W_C3 --steps 1 --warmup 1 $COMMON
-# BASELINE configs[4] per-GPU share (1B model, 1024 px = 128x128 tokens, batch 16, S = 264: encode -> masked renoise -> 2 sampling steps -> decode)
-trace config5_b16_128x128_inpaint_test 16 env PYTHONPATH=$R python -m pytest $R/tests/test_gpu_sample.py --rootdir $R -q -p no:cacheprovider -k config5_full_size
+# BASELINE configs[3] / configs[4] per-GPU shares as bench.py times them (released-size 1B model, ByT5 256 + CLIP text + CLIP image; configs[4] = the inpainting path); eager, 2 batches each
+W_C4="python $R/bench.py --model 1b --batch 32 --grid 64 --sample-steps 12 --s-byt5 256 --clip-image 1"
+W_C5="python $R/bench.py --model 1b --batch 16 --grid 128 --sample-steps 12 --s-byt5 256 --clip-image 1 --inpaint"
+trace configs3_share_1b_b32_64x64 64 $W_C4 --steps 1 --warmup 0 $COMMON
+trace configs4_share_1b_b16_128x128_inpaint 32 $W_C5 --steps 1 --warmup 0 $COMMON
+# the opt-in bf16 fast mode (outside the parity contract): the same three 570M workloads
+trace bf16_fastmode_b1_570m 6 $W_B1 --gemm bf16 --steps 4 --warmup 1 $COMMON
+trace bf16_fastmode_b32_570m 96 $W_B32 --gemm bf16 --steps 1 --warmup 1 $COMMON
+trace bf16_fastmode_config3_b64_64x64 192 $W_C3 --gemm bf16 --steps 1 --warmup 1 $COMMON
 
 traffic() {  # name, batch grid sample_steps, command...
     local name=$1 b=$2 g=$3 s=$4; shift 4
@@ -48,14 +55,20 @@ mfma() {  # name, command...
 mfma b1 $W_B1 --steps 2 --warmup 1 $COMMON
 mfma b32 $W_B32 --steps 1 --warmup 1 $COMMON
 mfma config3 $W_C3 --steps 1 --warmup 0 $COMMON
+mfma bf16_fastmode_config3 $W_C3 --gemm bf16 --steps 1 --warmup 0 $COMMON
 # per-shape GEMM time inside the model (event-timed, eager): where the image's milliseconds go
 cd $R
 python tools/gemm_by_shape.py 2>&1 | grep -v amdgpu > $O/${TAG}_gemm_by_shape_b1.txt
 python tools/gemm_by_shape.py --batch 32 2>&1 | grep -v amdgpu > $O/${TAG}_gemm_by_shape_b32.txt
 python tools/gemm_by_shape.py --batch 64 --grid 64 --sample-steps 2 2>&1 | grep -v amdgpu > $O/${TAG}_gemm_by_shape_config3_2steps.txt
+python tools/gemm_by_shape.py --gemm bf16 2>&1 | grep -v amdgpu > $O/${TAG}_gemm_by_shape_bf16_b1.txt
+python tools/gemm_by_shape.py --gemm bf16 --batch 32 2>&1 | grep -v amdgpu > $O/${TAG}_gemm_by_shape_bf16_b32.txt
+python tools/gemm_by_shape.py --gemm bf16 --batch 64 --grid 64 --sample-steps 2 2>&1 | grep -v amdgpu > $O/${TAG}_gemm_by_shape_bf16_config3_2steps.txt
 # the parity report: every oracle / reference comparison with its near-tie counts printed (-s)
 { echo "# python -m pytest tests -m gpu -q -s -k 'parity or vs_oracle or vs_reference or closed_loop or benchmarked or geometry or train_step or prompts_to_image or graph_sampler or reproduces or grn_finished'   (MI355X)"
   python -m pytest tests -m gpu -q -s -p no:cacheprovider -k "parity or vs_oracle or vs_reference or closed_loop or benchmarked or geometry or train_step or prompts_to_image or graph_sampler or reproduces or grn_finished" 2>&1 | grep -v "amdgpu.ids" | grep -v "^\s*$"; } > $O/${TAG}_parity_report.txt
+{ echo "# python -m pytest tests/test_gpu_fastmode.py tests/test_gpu_unet.py -q -s -k 'forward_deviation or sampling_fused or vqgan or layernorm_guard'   (MI355X): bf16 fast mode deviation / flip rates; LayerNorm guard inside the network"
+  python -m pytest tests/test_gpu_fastmode.py tests/test_gpu_unet.py -q -s -p no:cacheprovider -k "forward_deviation or sampling_fused or vqgan or layernorm_guard" 2>&1 | grep "fast mode\|guard in the network\|sampled tokens\|passed\|failed" | sed 's/^[.F]*//'; } > $O/${TAG}_fastmode_and_ln_guard_report.txt
 # round 4: the LayerNorm-fold error curve (threshold hook at inf / 0 / default), the RCCL path at the box's world size
 { echo "# python -m pytest tests/test_gpu_ops.py -q -s -k layernorm_fold   (MI355X): max |out - fp64| of a LayerNorm-consuming GEMM, K = 1280, outputs of unit scale, per |row mean| / std"
   python -m pytest tests/test_gpu_ops.py -q -s -p no:cacheprovider -k "layernorm_fold" 2>&1 | grep "cfg\|passed\|failed" | sed 's/^[.F]*//'; } > $O/${TAG}_ln_fold_error_curve.txt
