@@ -196,7 +196,12 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
 // Same arithmetic in the same order as the register-fed kernel above (16-key steps walked in key order per wave): results are
 // bit-identical to it.
 // ---------------------------------------------------------------------------------------------------------------------------------
-template <int DT>
+// VAR (A/B through the test hook; the arithmetic per query is the same in every variant -> bit-identical outputs):
+//   0 = one 16-key sub-tile at a time: K fragments -> 20 DEPENDENT S MFMAs -> softmax -> 5 x 4 dependent PV MFMAs (rounds 2-4)
+//   1 = both sub-tiles' S chains of a 32-key stage issued together, alternating accumulators (no two consecutive MFMAs share one; the second chain's results
+//       are in flight while the first sub-tile's softmax runs), PV MFMAs ordered e-outer so that consecutive ones hit different accumulators
+//   2 = variant 1 + s_setprio 1 around the MFMA blocks (a wave in its matrix phase wins issue arbitration against the SIMD's other waves' VALU phases)
+template <int DT, int VAR = 0>
 __global__ __launch_bounds__(256) void attention_lds_kernel(AttnArgs args) {
     constexpr int D = DT * 16, D4 = D / 4;
     constexpr int KTILE = 32;                 // keys per LDS stage
@@ -266,16 +271,8 @@ __global__ __launch_bounds__(256) void attention_lds_kernel(AttnArgs args) {
     for (int j = 0; j < DT; ++j) oacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.f;
 
-    auto process16 = [&](int key0, const float* Ks, const float* Vs) __attribute__((always_inline)) {  // 16 keys starting at key0; Ks / Vs = this sub-tile's rows
-        f32x4 kf[DT];
-        const float* kp = Ks + r16 * PITCH + kq * 4;
-#pragma unroll
-        for (int j = 0; j < DT; ++j) kf[j] = *reinterpret_cast<const f32x4*>(kp + j * 16);
-        f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < DT; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[j][e], qf[j][e], s, 0, 0, 0);
+    // second half of a 16-key step: online softmax over S^T (lane (r16, kq) holds the scores of query r16 against keys key0 + 4 * kq + 0..3), then O^T += V^T . P^T
+    auto softmax_pv = [&](int key0, const f32x4 s, const float* Vs) __attribute__((always_inline)) {
         float vf[DT][4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -312,11 +309,51 @@ __global__ __launch_bounds__(256) void attention_lds_kernel(AttnArgs args) {
             }
         }
 #pragma unroll
-        for (int j = 0; j < DT; ++j) {
-            oacc[j] *= alpha;
+        for (int j = 0; j < DT; ++j) oacc[j] *= alpha;
+        if (VAR == 2) __builtin_amdgcn_s_setprio(1);
+        if (VAR == 0) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) oacc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[j][e], p[e], oacc[j], 0, 0, 0);
+            for (int j = 0; j < DT; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) oacc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[j][e], p[e], oacc[j], 0, 0, 0);
+        } else {  // same four accumulations per oacc[j] in the same order (e = 0..3); consecutive MFMAs hit different accumulators
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int j = 0; j < DT; ++j) oacc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[j][e], p[e], oacc[j], 0, 0, 0);
         }
+        if (VAR == 2) __builtin_amdgcn_s_setprio(0);
+    };
+    auto process16 = [&](int key0, const float* Ks, const float* Vs) __attribute__((always_inline)) {  // 16 keys starting at key0; Ks / Vs = this sub-tile's rows
+        f32x4 kf[DT];
+        const float* kp = Ks + r16 * PITCH + kq * 4;
+#pragma unroll
+        for (int j = 0; j < DT; ++j) kf[j] = *reinterpret_cast<const f32x4*>(kp + j * 16);
+        f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < DT; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[j][e], qf[j][e], s, 0, 0, 0);
+        softmax_pv(key0, s, Vs);
+    };
+    // a whole 32-key stage: both S chains first (two accumulators, alternating), then the two softmax / PV halves in key order
+    auto process32 = [&](int key0, const float* Ks, const float* Vs, bool second) __attribute__((always_inline)) {
+        f32x4 kf0[DT], kf1[DT];
+        const float* kp = Ks + r16 * PITCH + kq * 4;
+#pragma unroll
+        for (int j = 0; j < DT; ++j) { kf0[j] = *reinterpret_cast<const f32x4*>(kp + j * 16); kf1[j] = *reinterpret_cast<const f32x4*>(kp + 16 * PITCH + j * 16); }
+        f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = s0;
+        if (VAR == 2) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int j = 0; j < DT; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf0[j][e], qf[j][e], s0, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf1[j][e], qf[j][e], s1, 0, 0, 0);
+            }
+        if (VAR == 2) __builtin_amdgcn_s_setprio(0);
+        softmax_pv(key0, s0, Vs);
+        if (second) softmax_pv(key0 + 16, s1, Vs + 16 * PITCH);
     };
 
     load_tile(0);
@@ -328,10 +365,14 @@ __global__ __launch_bounds__(256) void attention_lds_kernel(AttnArgs args) {
         __builtin_amdgcn_sched_barrier(0);
         const float* Ks = smem + slot * STAGE;
         const float* Vs = Ks + KTILE * PITCH;
+        if constexpr (VAR == 0) {
 #pragma unroll
-        for (int sub = 0; sub < KTILE / 16; ++sub)
-            if (kt * KTILE + sub * 16 < Lk)  // workgroup-uniform: skip a fully masked half tile
-                process16(kt * KTILE + sub * 16, Ks + sub * 16 * PITCH, Vs + sub * 16 * PITCH);
+            for (int sub = 0; sub < KTILE / 16; ++sub)
+                if (kt * KTILE + sub * 16 < Lk)  // workgroup-uniform: skip a fully masked half tile
+                    process16(kt * KTILE + sub * 16, Ks + sub * 16 * PITCH, Vs + sub * 16 * PITCH);
+        } else {
+            process32(kt * KTILE, Ks, Vs, kt * KTILE + 16 < Lk);  // (a fully masked second half is multiplied -- clamped rows -- and dropped)
+        }
         __builtin_amdgcn_sched_barrier(0);
         store_tile(slot ^ 1);
         __syncthreads();
@@ -352,7 +393,7 @@ __global__ __launch_bounds__(256) void attention_lds_kernel(AttnArgs args) {
     }
 }
 
-static std::atomic<int> g_attn_variant{0};  // test hook (test_hooks.h): 1 = force the register-fed kernel for large query counts too (A/B probes)
+static std::atomic<int> g_attn_variant{0};  // test hook (test_hooks.h): 1 = force the register-fed kernel for large query counts too; 10 / 11 / 12 = LDS-staged kernel variant 0 / 1 / 2 at head_dim 80 (A/B probes)
 extern "C" int paella_test_attention_variant(int v) { g_attn_variant = v; return PAELLA_OK; }
 
 int launch_attention(const AttnArgs& a, hipStream_t st) {
@@ -378,6 +419,14 @@ int launch_attention(const AttnArgs& a, hipStream_t st) {
         else if (lds) hipLaunchKernelGGL((attention_lds_kernel<n>), grid, dim3(256), 0, st, a);            \
         else hipLaunchKernelGGL((attention_kernel<n, false>), grid, dim3(256), 0, st, a);                  \
         break;
+    const int variant = g_attn_variant.load();
+    if (lds && a.D == 80 && variant >= 10 && variant <= 12) {
+        if (variant == 10) hipLaunchKernelGGL((attention_lds_kernel<5, 0>), grid, dim3(256), 0, st, a);
+        else if (variant == 11) hipLaunchKernelGGL((attention_lds_kernel<5, 1>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((attention_lds_kernel<5, 2>), grid, dim3(256), 0, st, a);
+        LAUNCH_CHECK_RET();
+        return PAELLA_OK;
+    }
     switch (a.D / 16) {
         case 1:  // head_dim 16 (toy models): the LDS-staged instantiation spills; the register-fed kernel serves large query counts there
             if (ksplit) hipLaunchKernelGGL((attention_kernel<1, true>), grid, dim3(256), 0, st, a);

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Same-box A/B of the cache policy of the ring tiles' WEIGHT stream: the product library (default policy) against a probe build of
-# gemm.hip with -DPAELLA_RING_W_AUX=2 (nt) linked into a second library; the two are swapped in place and the batch-1 headline is timed alternately.
+# gemm.hip with the OTHER policy (-DPAELLA_RING_W_AUX=0 since nt became the default in round 5; the committed profile was measured with 0 as the default and 2 as
+# the probe) linked into a second library; the two are swapped in place and the batch-1 headline is timed alternately.
 # Usage (GPU box, repo root): bash tools/ab_nt_weights.sh > gpurun_out/ring_nt_weights_ab.txt
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 C=$R/paella_amd/csrc
