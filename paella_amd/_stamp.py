@@ -17,11 +17,14 @@ def source_files():
 # the compile configuration is part of what a library was "built from": changing a flag or the target must not reuse stale objects
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# per-unit extras.  attention.hip: keep the MFMA accumulators in VGPRs -- the online softmax rescales O^T between every two MFMA blocks, and with AGPR accumulators
+# hipcc moved all 20 of them out and back per 16-key step (148 v_accvgpr_* per 32 keys; profiles/r05_attention_pmc_and_probe.txt)
+UNIT_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def source_stamp():
     h = hashlib.sha256()
-    h.update(" ".join(FLAGS).encode())
+    h.update((" ".join(FLAGS) + repr(sorted(UNIT_FLAGS.items()))).encode())
     for path in source_files():
         h.update(os.path.basename(path).encode())
         with open(path, "rb") as f:

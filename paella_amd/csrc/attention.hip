@@ -23,6 +23,11 @@
 
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));  // bf16 output of the opt-in fast mode (AttnArgs::out16)
 
+// exp on the hardware exp2 (v_exp_f32 of x * log2 e: 2 instructions, relative error ~1e-7 * (1 + |x|)) instead of the libm sequence (14 instructions, 5 calls
+// per 16-key step and lane: the softmax VALU phase is where the matrix core idles -- profiles/r05_attention_pmc_and_probe.txt).  exp_fast(-inf) = 0 as the
+// masking relies on.  Every attention kernel uses this one function, so the LDS-staged and register-fed kernels stay bit-identical to each other.
+__device__ __forceinline__ float exp_fast(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+
 // KSPLIT = true : one workgroup per 16 queries, its 4 waves split the key tiles (latency-bound small grids)
 // KSPLIT = false: one workgroup per 64 queries, each wave owns 16 queries and walks all key tiles (K/V re-read 16x less)
 template <int DT, bool KSPLIT>  // DT = head_dim / 16
@@ -94,11 +99,11 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
         mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
         mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
         const float m_new = fmaxf(m_run, mt);
-        const float alpha = expf(m_run - m_new);  // first tile: exp(-inf) = 0
+        const float alpha = exp_fast(m_run - m_new);  // first tile: exp(-inf) = 0
         float psum = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            p[r] = expf(p[r] - m_new);  // masked keys: exp(-inf) = 0, which also zeroes their (clamped) V rows
+            p[r] = exp_fast(p[r] - m_new);  // masked keys: exp(-inf) = 0, which also zeroes their (clamped) V rows
             psum += p[r];
         }
         l_run = l_run * alpha + psum;  // per-lane partial; lanes of equal r16 are combined at the end
@@ -166,7 +171,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
     float l_all = 0.f, f[4];
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
-        f[w] = expf(mw[w] - m_all);  // empty waves: exp(-inf) = 0
+        f[w] = exp_fast(mw[w] - m_all);  // empty waves: exp(-inf) = 0
         l_all += s_l[w][lane] * f[w];
     }
     const float inv = 1.0f / l_all;
@@ -201,7 +206,9 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
 //   1 = both sub-tiles' S chains of a 32-key stage issued together, alternating accumulators (no two consecutive MFMAs share one; the second chain's results
 //       are in flight while the first sub-tile's softmax runs), PV MFMAs ordered e-outer so that consecutive ones hit different accumulators
 //   2 = variant 1 + s_setprio 1 around the MFMA blocks (a wave in its matrix phase wins issue arbitration against the SIMD's other waves' VALU phases)
-template <int DT, int VAR = 0>
+//   3 = variant 1 + ONE static priority per workgroup, (blockIdx.x + y + z) % 3: the three waves that share a SIMD come from three workgroups; with distinct
+//       priorities the highest runs its serial chain at full speed and the others fill its VALU phases instead of all three convoying through the matrix core
+template <int DT, int VAR = 1>
 __global__ __launch_bounds__(256) void attention_lds_kernel(AttnArgs args) {
     constexpr int D = DT * 16, D4 = D / 4;
     constexpr int KTILE = 32;                 // keys per LDS stage
@@ -224,6 +231,11 @@ __global__ __launch_bounds__(256) void attention_lds_kernel(AttnArgs args) {
     const int r16 = lane & 15, kq = lane >> 4;
     const int Lk = Lself + Lcond;
     const int ntiles = (Lk + KTILE - 1) / KTILE;
+    if constexpr (VAR == 3) {
+        const unsigned pr = (blockIdx.x + blockIdx.y + blockIdx.z) % 3u;
+        if (pr == 2) __builtin_amdgcn_s_setprio(2);
+        else if (pr == 1) __builtin_amdgcn_s_setprio(1);
+    }
 
     f32x4 qf[DT];
     {
@@ -291,11 +303,11 @@ __global__ __launch_bounds__(256) void attention_lds_kernel(AttnArgs args) {
         mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
         mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
         const float m_new = fmaxf(m_run, mt);
-        const float alpha = expf(m_run - m_new);  // first tile: exp(-inf) = 0
+        const float alpha = exp_fast(m_run - m_new);  // first tile: exp(-inf) = 0
         float psum = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            p[r] = expf(p[r] - m_new);  // masked keys: exp(-inf) = 0, which also zeroes their (clamped) V rows
+            p[r] = exp_fast(p[r] - m_new);  // masked keys: exp(-inf) = 0, which also zeroes their (clamped) V rows
             psum += p[r];
         }
         l_run = l_run * alpha + psum;
@@ -420,10 +432,11 @@ int launch_attention(const AttnArgs& a, hipStream_t st) {
         else hipLaunchKernelGGL((attention_kernel<n, false>), grid, dim3(256), 0, st, a);                  \
         break;
     const int variant = g_attn_variant.load();
-    if (lds && a.D == 80 && variant >= 10 && variant <= 12) {
+    if (lds && a.D == 80 && variant >= 10 && variant <= 13) {
         if (variant == 10) hipLaunchKernelGGL((attention_lds_kernel<5, 0>), grid, dim3(256), 0, st, a);
         else if (variant == 11) hipLaunchKernelGGL((attention_lds_kernel<5, 1>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((attention_lds_kernel<5, 2>), grid, dim3(256), 0, st, a);
+        else if (variant == 12) hipLaunchKernelGGL((attention_lds_kernel<5, 2>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((attention_lds_kernel<5, 3>), grid, dim3(256), 0, st, a);
         LAUNCH_CHECK_RET();
         return PAELLA_OK;
     }

@@ -11,6 +11,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
 OBJS=""
 for u in gemm elementwise dwconv attention tail vqgan model vqmodel; do
   if [ $u = gemm ]; then /opt/rocm/bin/hipcc $FLAGS -DPAELLA_RING_W_AUX=2 -c $C/gemm.hip -o $T/gemm.o 2>/dev/null
+  elif [ $u = attention ]; then /opt/rocm/bin/hipcc $FLAGS -mllvm -amdgpu-mfma-vgpr-form=1 -c $C/$u.hip -o $T/$u.o 2>/dev/null &
   else /opt/rocm/bin/hipcc $FLAGS -c $C/$u.hip -o $T/$u.o 2>/dev/null & fi
   OBJS="$OBJS $T/$u.o"
 done

@@ -20,7 +20,7 @@ for (B, Lq, Lcond) in [(32, 256, 776), (32, 1024, 776), (8, 4096, 776), (128, 25
     qkv = torch.randn(B * Lq, 3 * c, device="cuda", generator=g)
     kvc = torch.randn(B * Lcond, 2 * c, device="cuda", generator=g)
     outs = []
-    for variant, name in ((1, "register-fed"), (0, "LDS-staged"), (10, "LDS var 0"), (11, "LDS var 1"), (12, "LDS var 2")):
+    for variant, name in ((1, "register-fed"), (0, "LDS-staged"), (10, "LDS var 0"), (11, "LDS var 1"), (12, "LDS var 2"), (13, "LDS var 3")):
         lib.paella_test_attention_variant(variant)
         out = torch.empty(B * Lq, c, device="cuda")
         # q / k / v are column blocks of the packed projection output, exactly as the model calls it (ld = 3c / 2c)
