@@ -1383,6 +1383,45 @@ static long ring_resident(int cfg, int apro) {
     }
 }
 
+// Per-launch-site workgroup counts of the skinny (ring-tile) class: the rules below are global fits; a site (M, N, K, operand prologue class, bf16) listed here takes
+// its own count instead.  Entries come from tools/site_tune.py -- coordinate descent over every distinct site of the batch-1 image INSIDE the captured graph,
+// two passes, same box (profiles/r05_site_tune_b1.txt) -- and can be overridden at run time through the test hook (what the tuner itself uses).
+struct SiteG { int M, N, K, apro, bf, G; };
+static SiteG g_sites[96] = {
+    // (filled from profiles/r05_site_tune_b1.txt; empty = global rules only)
+};
+static std::atomic<int> g_nsites{0};
+static int g_nsites_builtin = -1;
+static int site_lookup(int M, int N, int K, int apro, int bf) {
+    if (g_nsites_builtin < 0) {  // count the built-in entries once (zero-initialised tail)
+        int n = 0;
+        while (n < 96 && g_sites[n].M > 0) ++n;
+        g_nsites_builtin = n;
+        int expect = 0;
+        g_nsites.compare_exchange_strong(expect, n);
+    }
+    const int n = g_nsites.load(std::memory_order_acquire);
+    for (int i = n - 1; i >= 0; --i)  // (later entries -- run-time overrides -- win)
+        if (g_sites[i].M == M && g_sites[i].N == N && g_sites[i].K == K && g_sites[i].apro == apro && g_sites[i].bf == bf) return g_sites[i].G;
+    return 0;
+}
+// test hook: G > 0 sets / overrides a site, G == 0 removes the run-time entries of that site, M == 0 removes every run-time entry
+extern "C" int paella_test_gemm_site(int M, int N, int K, int apro, int bf, int G) {
+    (void)site_lookup(1, 1, 1, 0, 0);
+    int n = g_nsites.load();
+    if (M == 0) { g_nsites = g_nsites_builtin; return PAELLA_OK; }
+    for (int i = n - 1; i >= g_nsites_builtin; --i)
+        if (g_sites[i].M == M && g_sites[i].N == N && g_sites[i].K == K && g_sites[i].apro == apro && g_sites[i].bf == bf) {
+            if (G > 0) { g_sites[i].G = G; return PAELLA_OK; }
+            g_sites[i] = g_sites[n - 1]; g_nsites = n - 1; return PAELLA_OK;
+        }
+    if (G <= 0) return PAELLA_OK;
+    if (n >= 96) { paella_set_error("site table full"); return PAELLA_ERR_STATE; }
+    g_sites[n] = SiteG{M, N, K, apro, bf, G};
+    g_nsites.store(n + 1, std::memory_order_release);
+    return PAELLA_OK;
+}
+
 // test hook (tests/test_kernel_resources.py): the table above, so that a CPU test can hold it against the occupancy the compiler actually produced
 extern "C" long paella_test_ring_resident(int cfg, int apro) { return (cfg >= 30 && cfg <= 35) ? ring_resident(cfg, apro) : -1; }
 
@@ -1431,6 +1470,7 @@ static void choose_config(int M, int N, int K, int apro, bool ring_allowed, int 
             const long U = Tc * ktiles;
             if (apro == 2) G = Tc >= 160 ? Tc : 2 * Tc;
             else G = U / 10;
+            if (const int gs = site_lookup(M, N, K, apro, 0)) G = gs;
             if (G < Tc) G = Tc;
             if (G > resident) G = resident;
         } else {
@@ -1503,7 +1543,8 @@ static void choose_config_bf16(int M, int N, int K, int apro, size_t slab_cap_by
         if (S < 1 || apro == 2) S = 1;
         G = Tc * S;
         const long resident = ring_resident(cfg, apro);
-        if (G > resident && S > 1) G = resident;
+        if (const int gs = site_lookup(M, N, K, apro, 1)) { G = gs; if (G < Tc) G = Tc; }
+        if (G > resident && G > Tc) G = resident;
     }
     const long T = tiles_of_cfg(cfg, M, N);
     const long U = T * ktiles;

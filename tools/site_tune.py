@@ -1,0 +1,106 @@
+"""Per-launch-site tuning of the workgroup count of the batch-1 GEMMs INSIDE the captured graph: for every distinct skinny site
+(M, N, K, operand prologue) of the headline image, coordinate descent over G -- re-capture the GraphSampler with the candidate installed through the test hook,
+time graph replays, keep the best -- two passes.  Prints a table and the C initialiser for gemm.hip's g_sites.
+Usage (GPU box): python tools/site_tune.py [--gemm bf16] [--reps 12] [--passes 2]"""
+import argparse
+import collections
+import ctypes
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import bench
+import paella_amd
+from paella_amd import _lib, synth
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--gemm", default="fp32", choices=["fp32", "bf16"])
+ap.add_argument("--reps", type=int, default=12)
+ap.add_argument("--passes", type=int, default=2)
+ap.add_argument("--max-macs", type=float, default=1.2e9, help="only sites of the skinny class (M*N*K below this)")
+a = ap.parse_args()
+lib = _lib.load()
+dev = torch.device("cuda")
+bf = 1 if a.gemm == "bf16" else 0
+mcfg, vcfg = bench.MODELS["570m"], bench.VQ["570m"]
+model = paella_amd.Paella(**mcfg)
+synth.randomize_(model, seed=0)
+model = model.to(dev)
+vq = paella_amd.VQModel(**vcfg)
+synth.randomize_(vq, seed=0)
+vq = vq.to(dev)
+model.set_gemm_precision(a.gemm)
+vq.set_gemm_precision(a.gemm)
+mk = lambda n, seed: synth.synth_conditioning(n, 0, mcfg["byt5_embd"], mcfg["clip_embd"], seed=seed, device=dev)
+c, u = mk(1, 2), mk(1, 3)
+kw = dict(steps=8, renoise_steps=7, temperature=(1.0, 0.2), cfg=8.0, device=dev)
+
+# the sites: one eager image with every GEMM launch recorded
+lib.paella_prof_enable(1)
+vq.decode_indices(paella_amd.sample(model, c, (1, 32, 32), unconditional_inputs=u, noise="philox", seed=1, **kw))
+torch.cuda.synchronize()
+cap = 1 << 15
+us = np.zeros(cap, dtype=np.float32)
+shp = np.zeros(cap * 5, dtype=np.int32)
+n = lib.paella_prof_detail(us.ctypes.data_as(ctypes.c_void_p), shp.ctypes.data_as(ctypes.c_void_p), cap)
+lib.paella_prof_enable(0)
+sites = collections.OrderedDict()
+for t, s5 in zip(us[:n], shp[:n * 5].reshape(n, 5)):
+    M, N, K, pro, tail = (int(v) for v in s5)
+    if tail or pro == 3 or float(M) * N * K >= a.max_macs or K % (64 if bf else 32):
+        continue
+    key = (M, N, K, 1 if pro in (1, 4) else (2 if pro == 2 else 0))
+    sites.setdefault(key, [0, 0.0])
+    sites[key][0] += 1
+    sites[key][1] += float(t)
+sites = collections.OrderedDict(sorted(sites.items(), key=lambda kv: -kv[1][1]))
+
+
+def measure():
+    gs = paella_amd.GraphSampler(model, c, u, (1, 32, 32), vqgan=vq, **kw)
+    for _ in range(2):
+        gs(seed=5)
+    torch.cuda.synchronize()
+    ts = []
+    for r in range(a.reps):
+        t0 = time.perf_counter()
+        gs(seed=7 + r)
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    ts.sort()
+    return sum(ts[:max(3, a.reps // 2)]) / max(3, a.reps // 2)   # mean of the faster half
+
+
+base = measure()
+print("# python tools/site_tune.py --gemm %s: %d skinny sites of the batch-1 image; baseline (global rules) %.3f ms per image (graph replay, mean of the faster half of %d)" % (a.gemm, len(sites), base, a.reps), flush=True)
+best = {}
+cur = base
+for p in range(a.passes):
+    for (M, N, K, apro), (calls, tot) in sites.items():
+        tiles = -(-M // 32) * -(-N // 32)
+        ksteps = K // (64 if bf else 32)
+        U = tiles * ksteps
+        cands = sorted(set(int(g) for g in (tiles, 2 * tiles, 3 * tiles, U // 16, U // 12, U // 10, U // 8, U // 6, U // 4, 512, 768, 1024, 1280) if tiles <= g <= min(U, 1280)))
+        res = {}
+        for g in cands:
+            lib.paella_test_gemm_site(M, N, K, apro, bf, g)
+            res[g] = measure()
+        gbest = min(res, key=res.get)
+        keep = res[gbest] < cur - 0.010   # below 10 us per image a difference is noise: keep the rule's choice
+        if keep:
+            lib.paella_test_gemm_site(M, N, K, apro, bf, gbest)
+            best[(M, N, K, apro)] = gbest
+            cur = res[gbest]
+        else:
+            lib.paella_test_gemm_site(M, N, K, apro, bf, best.get((M, N, K, apro), 0))
+        print("pass %d site %5dx%5dx%5d pro %d (%3d launches, %.2f ms event-timed): " % (p, M, N, K, apro, calls, tot / 1e3) +
+              " ".join("%d:%.3f" % (g, res[g]) for g in cands) + ("  -> G = %d (%.3f ms)" % (gbest, res[gbest]) if keep else "  -> rule kept"), flush=True)
+final = measure()
+print("# final %.3f ms per image against %.3f with the global rules (%.2f %%)" % (final, base, (final / base - 1) * 100))
+print("# g_sites initialiser:")
+for (M, N, K, apro), g in best.items():
+    print("    {%d, %d, %d, %d, %d, %d}," % (M, N, K, apro, bf, g))
