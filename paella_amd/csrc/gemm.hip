@@ -1388,7 +1388,13 @@ static long ring_resident(int cfg, int apro) {
 // two passes, same box (profiles/r05_site_tune_b1.txt) -- and can be overridden at run time through the test hook (what the tuner itself uses).
 struct SiteG { int M, N, K, apro, bf, G; };
 static SiteG g_sites[96] = {
-    // (filled from profiles/r05_site_tune_b1.txt; empty = global rules only)
+    // profiles/r05_site_tune_b1.txt: 27 skinny sites of the batch-1 image swept, 5 moved (22.47 -> 22.24 ms per image on the tuning box, -1.0 %; the second pass changed
+    // nothing); everywhere else the global rules sit within 30 us per image of the best candidate
+    {128, 1280, 1280, 0, 0, 768},   // attention out-projection, 64-position level (rule: 640)
+    {32, 1280, 5120, 1, 0, 400},    // MLP out with the GRN prologue, 16-position level (rule: 640)
+    {32, 5120, 1280, 0, 0, 768},    // MLP in, 16-position level (rule: 640)
+    {32, 1280, 1280, 0, 0, 200},    // attention out-projection, 16-position level (rule: 160)
+    {1024, 384, 1536, 0, 0, 768},   // VQGAN bottleneck MLP out (rule: 1280)
 };
 static std::atomic<int> g_nsites{0};
 static int g_nsites_builtin = -1;
