@@ -405,6 +405,166 @@ __global__ __launch_bounds__(256) void attention_lds_kernel(AttnArgs args) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// OPT-IN bf16 fast mode (outside the fp32 parity contract), >= 256 queries: the LDS-staged kernel with both contractions on v_mfma_f32_16x16x16_bf16.
+// q / self K / self V arrive as bf16 (the in-projection's epilogue copy), the conditioning K / V as the fp32 cache, rounded while staged; the online softmax
+// stays fp32 (exp_fast), the probabilities are rounded to bf16 for the second contraction (they are its B operand as they sit in the lane), output bf16.
+//   K tile  [32 keys][D + 8] bf16: a lane's S fragment is 8 contiguous bytes of one key row (ds_read_b64); pitch 2D + 16 bytes = 16 * odd -> conflict-free
+//   V tile  TRANSPOSED [D][32 + 8] bf16: a lane's PV fragment is V[key = 4 kq .. + 3][d = 16 j + r16] = 8 contiguous bytes of row d (ds_read_b64)
+// The matrix cores are no longer the bound (40 + 40 MFMA cycles per 16-key step against 1 280 in fp32): the step is its softmax VALU and LDS traffic.
+// ---------------------------------------------------------------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+template <int DT>
+__global__ __launch_bounds__(256) void attention_bf16_kernel(AttnArgs args) {
+    constexpr int D = DT * 16, D8 = D / 8;
+    constexpr int KTILE = 32;
+    constexpr int PK = D + 8;                  // K row pitch (bf16 elements)
+    constexpr int PV = KTILE + 8;              // V^T row pitch
+    constexpr int STAGE = KTILE * PK + D * PV; // elements per stage
+    constexpr int NITEM = KTILE * D8;          // 16-byte items per tensor and stage
+    constexpr int NL = (NITEM + 255) / 256;
+    __shared__ __attribute__((aligned(16))) unsigned short smem[2 * STAGE];
+
+    const int Lq = args.Lq, Lself = args.Lself, Lcond = args.Lcond, ld16 = args.ld16, ld_cond = args.ld_cond, ldo = args.ldo;
+    const int n_kw = args.n_kw;
+    const float scale = args.scale;
+    const float* const key_weights = args.key_weights;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q0 = (blockIdx.x * 4 + wave) * 16;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int Lk = Lself + Lcond;
+    const int ntiles = (Lk + KTILE - 1) / KTILE;
+
+    s16x4 qf[DT];  // Q[q0 + r16][16 j + 4 kq .. + 3]
+    {
+        const int q = min(q0 + r16, Lq - 1);
+        const unsigned short* qp = args.q16 + ((size_t)b * Lq + q) * ld16 + h * D + kq * 4;
+#pragma unroll
+        for (int j = 0; j < DT; ++j) qf[j] = *reinterpret_cast<const s16x4*>(qp + j * 16);
+    }
+    const unsigned short* ks_base = Lself ? args.k_self16 + (size_t)b * Lself * ld16 + h * D : nullptr;
+    const unsigned short* vs_base = Lself ? args.v_self16 + (size_t)b * Lself * ld16 + h * D : nullptr;
+    const float* kc_base = Lcond ? args.k_cond + (size_t)b * Lcond * ld_cond + h * D : nullptr;
+    const float* vc_base = Lcond ? args.v_cond + (size_t)b * Lcond * ld_cond + h * D : nullptr;
+
+    bf16x8 stk[NL], stv[NL];
+    auto load_tile = [&](int kt) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int idx = min(tid + i * 256, NITEM - 1);
+            const int key_in = idx / D8, c8 = idx - key_in * D8;
+            const int key = min(kt * KTILE + key_in, Lk - 1);
+            if (key < Lself) {
+                const size_t off = (size_t)key * ld16 + c8 * 8;
+                stk[i] = *reinterpret_cast<const bf16x8*>(ks_base + off);
+                stv[i] = *reinterpret_cast<const bf16x8*>(vs_base + off);
+            } else {
+                const size_t off = (size_t)(key - Lself) * ld_cond + c8 * 8;
+                const f32x4 k0 = *reinterpret_cast<const f32x4*>(kc_base + off), k1 = *reinterpret_cast<const f32x4*>(kc_base + off + 4);
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(vc_base + off), v1 = *reinterpret_cast<const f32x4*>(vc_base + off + 4);
+                stk[i] = __builtin_convertvector((f32x8){k0[0], k0[1], k0[2], k0[3], k1[0], k1[1], k1[2], k1[3]}, bf16x8);
+                stv[i] = __builtin_convertvector((f32x8){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]}, bf16x8);
+            }
+        }
+    };
+    auto store_tile = [&](int slot) __attribute__((always_inline)) {
+        unsigned short* Kt = smem + slot * STAGE;
+        unsigned short* Vt = Kt + KTILE * PK;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int idx = tid + i * 256;
+            if (NL * 256 == NITEM || idx < NITEM) {
+                const int key_in = idx / D8, c8 = idx - key_in * D8;
+                *reinterpret_cast<bf16x8*>(Kt + key_in * PK + c8 * 8) = stk[i];
+                const __attribute__((ext_vector_type(8))) unsigned short vb = __builtin_bit_cast(__attribute__((ext_vector_type(8))) unsigned short, stv[i]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) Vt[(c8 * 8 + e) * PV + key_in] = vb[e];  // transposed: row = d, column = key
+            }
+        }
+    };
+
+    f32x4 oacc[DT];
+#pragma unroll
+    for (int j = 0; j < DT; ++j) oacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+
+    auto process16 = [&](int key0, const unsigned short* Ks, const unsigned short* Vts) __attribute__((always_inline)) {  // Ks: this sub-tile's 16 key rows; Vts: V^T + its 16 key columns
+        f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+        const unsigned short* kp = Ks + r16 * PK + kq * 4;
+#pragma unroll
+        for (int j = 0; j < DT; ++j) s = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(*reinterpret_cast<const s16x4*>(kp + j * 16), qf[j], s, 0, 0, 0);
+        s16x4 vf[DT];
+#pragma unroll
+        for (int j = 0; j < DT; ++j) vf[j] = *reinterpret_cast<const s16x4*>(Vts + (j * 16 + r16) * PV + kq * 4);
+        float p[4];
+        float mt = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = key0 + kq * 4 + r;
+            p[r] = key < Lk ? s[r] * scale : -INFINITY;
+            mt = fmaxf(mt, p[r]);
+        }
+        mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float m_new = fmaxf(m_run, mt);
+        const float alpha = exp_fast(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            p[r] = exp_fast(p[r] - m_new);
+            psum += p[r];
+        }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+        if (key_weights) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int wi = key0 + kq * 4 + r - (Lk - n_kw);
+                const float wv = key_weights[min(max(wi, 0), n_kw - 1)];
+                if (wi >= 0 && wi < n_kw) p[r] *= wv;
+            }
+        }
+        const s16x4 pb = __builtin_bit_cast(s16x4, __builtin_convertvector((f32x4){p[0], p[1], p[2], p[3]}, bf16x4));
+#pragma unroll
+        for (int j = 0; j < DT; ++j) {
+            oacc[j] *= alpha;
+            oacc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf[j], pb, oacc[j], 0, 0, 0);
+        }
+    };
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int slot = kt & 1;
+        load_tile(min(kt + 1, ntiles - 1));
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned short* Ks = smem + slot * STAGE;
+        const unsigned short* Vt = Ks + KTILE * PK;
+#pragma unroll
+        for (int sub = 0; sub < KTILE / 16; ++sub)
+            if (kt * KTILE + sub * 16 < Lk) process16(kt * KTILE + sub * 16, Ks + sub * 16 * PK, Vt + sub * 16);
+        __builtin_amdgcn_sched_barrier(0);
+        store_tile(slot ^ 1);
+        __syncthreads();
+    }
+    float l = l_run;
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    const int q = q0 + r16;
+    if (q < Lq) {
+        unsigned short* op = args.out16 + ((size_t)b * Lq + q) * ldo + h * D + kq * 4;
+#pragma unroll
+        for (int j = 0; j < DT; ++j) *reinterpret_cast<bf16x4*>(op + j * 16) = __builtin_convertvector(oacc[j] * inv, bf16x4);
+    }
+}
+
 static std::atomic<int> g_attn_variant{0};  // test hook (test_hooks.h): 1 = force the register-fed kernel for large query counts too; 10 / 11 / 12 = LDS-staged kernel variant 0 / 1 / 2 at head_dim 80 (A/B probes)
 extern "C" int paella_test_attention_variant(int v) { g_attn_variant = v; return PAELLA_OK; }
 
@@ -420,6 +580,19 @@ int launch_attention(const AttnArgs& a, hipStream_t st) {
         return PAELLA_ERR_ARG;
     }
     if (a.key_weights && (a.n_kw > a.Lself + a.Lcond || a.n_kw < 1)) { paella_set_error("attention: attn_weights longer than the key sequence"); return PAELLA_ERR_ARG; }
+    if (a.q16) {  // opt-in bf16 fast mode (the model only asks for it at >= 256 queries)
+        if (!a.out16 || (a.Lself && (!a.k_self16 || !a.v_self16)) || (a.ld16 & 7) || (a.Lcond && (a.ld_cond & 3)) || (a.ldo & 3) || a.D % 16) {
+            paella_set_error("attention (bf16): needs out16, bf16 self K / V, ld16 %% 8 == 0");
+            return PAELLA_ERR_ARG;
+        }
+        dim3 grid16((a.Lq + 63) / 64, a.nhead, a.B);
+#define ATT16_CASE(n) case n: hipLaunchKernelGGL((attention_bf16_kernel<n>), grid16, dim3(256), 0, st, a); break;
+        switch (a.D / 16) { ATT16_CASE(2) ATT16_CASE(3) ATT16_CASE(4) ATT16_CASE(5) ATT16_CASE(6) ATT16_CASE(7) ATT16_CASE(8)
+            default: paella_set_error("attention (bf16): head_dim %d unsupported", a.D); return PAELLA_ERR_ARG; }
+#undef ATT16_CASE
+        LAUNCH_CHECK_RET();
+        return PAELLA_OK;
+    }
     // small query counts (batch-1 sampling grids) are latency chains -> split keys over waves; large ones re-read K/V
     // once per workgroup, so give a workgroup 64 queries instead
     const bool ksplit = a.Lq < 256;

@@ -252,6 +252,9 @@ struct AttnArgs {
     const float* key_weights;         // [n_kw] post-softmax multipliers for the LAST n_kw keys, or null
     int n_kw;
     unsigned short* out16;            // optional: the output rounded to bf16 at the same [row, ldo] positions INSTEAD of `out` (opt-in fast mode: feeds the out-projection)
+    // opt-in bf16 fast mode, large query counts (attention_bf16_kernel): q / self k / self v as bf16 column blocks of one buffer (leading dimension ld16 elements),
+    // both contractions on v_mfma_f32_16x16x16_bf16 (softmax in fp32; the conditioning K / V stay the fp32 cache and are rounded while staged).  q16 == null -> fp32 kernels
+    const unsigned short* q16; const unsigned short* k_self16; const unsigned short* v_self16; int ld16;
 };
 int launch_attention(const AttnArgs& a, hipStream_t stream);
 

@@ -827,6 +827,9 @@ static int run_attn_block(FwdCtx& cx, const Block& b, float* x, int h, int w) {
         RET_IF(launch_layernorm(x, cx.f.h, rows, ch, 1e-6f, 1.f, 0.f, 0, 0, 0, cx.st));
     }
     gq.ep.bias = T(m, b.prefix + ".attention.attn.in_proj_bias");
+    // bf16 fast mode at >= 256 queries: q / k / v leave the in-projection as bf16 only and the attention core runs on bf16 MFMA (attention_bf16_kernel)
+    const bool attn16 = wq16 && wo16 && h * w >= 256 && (nq % 8) == 0 && ((ch / nh) % 16) == 0 && ch / nh >= 32;
+    if (attn16) { gq.C = nullptr; gq.ep.c16 = cx.f.g16; }
     RET_IF(launch_gemm(gq, cx.f.splitk, kSplitKBudget, cx.st));
     const float* kv = cx.cond + m->kv_col[b.attn_index];
     AttnArgs a;
@@ -838,6 +841,11 @@ static int run_attn_block(FwdCtx& cx, const Block& b, float* x, int h, int w) {
     a.scale = 1.0f / sqrtf((float)(ch / nh));
     a.key_weights = cx.attn_w; a.n_kw = cx.n_aw;
     a.out16 = wo16 ? cx.f.h16 : nullptr;
+    a.q16 = nullptr; a.k_self16 = nullptr; a.v_self16 = nullptr; a.ld16 = 0;
+    if (attn16) {
+        a.q16 = cx.f.g16; a.ld16 = nq;
+        a.k_self16 = self ? cx.f.g16 + ch : nullptr; a.v_self16 = self ? cx.f.g16 + 2 * ch : nullptr;
+    }
     RET_IF(launch_attention(a, cx.st));
     GemmArgs go = gemm_args(cx.f.h, ch, T(m, b.prefix + ".attention.attn.out_proj.weight"), ch, x, ch, (int)rows, ch, ch);
     if (wo16) { go.A16 = cx.f.h16; go.W16 = wo16; }
@@ -1192,5 +1200,17 @@ extern "C" int paella_op_attention(const float* q, const float* k_self, const fl
     a.q = q; a.ldq = ld; a.k_self = k_self; a.v_self = v_self; a.ld_self = ld; a.k_cond = k_cond; a.v_cond = v_cond; a.ld_cond = ld;
     a.out = out; a.ldo = ld; a.B = B; a.nhead = nhead; a.D = D; a.Lq = Lq; a.Lself = Lself; a.Lcond = Lcond;
     a.scale = 1.0f / sqrtf((float)D); a.key_weights = key_weights; a.n_kw = key_weights ? n_kw : 0; a.out16 = nullptr;
+    a.q16 = nullptr; a.k_self16 = nullptr; a.v_self16 = nullptr; a.ld16 = 0;
+    return launch_attention(a, (hipStream_t)stream);
+}
+// test hook (test_hooks.h): the bf16 attention core of the opt-in fast mode on caller-provided operands: q16 / ks16 / vs16 bf16 [B*L, nhead*D], kc / vc fp32, out16 bf16
+extern "C" int paella_test_attention_bf16(const unsigned short* q16, const unsigned short* ks16, const unsigned short* vs16, const float* k_cond, const float* v_cond,
+                                          unsigned short* out16, int B, int nhead, int D, int Lq, int Lself, int Lcond, const float* key_weights, int n_kw, void* stream) {
+    AttnArgs a;
+    const int ld = nhead * D;
+    a.q = nullptr; a.ldq = ld; a.k_self = nullptr; a.v_self = nullptr; a.ld_self = ld; a.k_cond = k_cond; a.v_cond = v_cond; a.ld_cond = ld;
+    a.out = nullptr; a.ldo = ld; a.B = B; a.nhead = nhead; a.D = D; a.Lq = Lq; a.Lself = Lself; a.Lcond = Lcond;
+    a.scale = 1.0f / sqrtf((float)D); a.key_weights = key_weights; a.n_kw = key_weights ? n_kw : 0; a.out16 = out16;
+    a.q16 = q16; a.k_self16 = ks16; a.v_self16 = vs16; a.ld16 = ld;
     return launch_attention(a, (hipStream_t)stream);
 }

@@ -221,3 +221,35 @@ def test_bf16_vqgan_decode_deviation_and_restore(built_lib):
     assert torch.isfinite(fast).all() and not torch.equal(fast, exact)
     assert diff <= 0.05 * max(1.0, scale)
     assert torch.equal(again, exact)
+
+
+@pytest.mark.parametrize("B,nh,D,Lq,Ls,Lc,nkw", [(2, 4, 80, 320, 320, 7, 0), (1, 2, 32, 256, 0, 100, 0), (2, 16, 80, 256, 256, 264, 5), (1, 3, 128, 300, 300, 33, 0)])
+def test_bf16_attention_core(built_lib, B, nh, D, Lq, Ls, Lc, nkw):
+    """attention_bf16_kernel (the fast mode's attention at >= 256 queries): both contractions on bf16 MFMA, softmax in fp32, probabilities rounded to bf16 for the
+    second contraction.  Reference: fp64 attention on the bf16-ROUNDED q / k / v (conditioning k / v are rounded by the kernel while staged); what remains is the
+    rounding of the probabilities (2^-9 relative each) and of the output: |err| <= 1.5e-2 on outputs of unit scale."""
+    lib = built_lib
+    g = torch.Generator().manual_seed(Lq * 3 + Lc)
+    C = nh * D
+    r = lambda *sh: torch.randn(*sh, generator=g).bfloat16()
+    q, ks, vs = r(B, Lq, C), r(B, Ls, C), r(B, Ls, C)
+    kc, vc = torch.randn(B, Lc, C, generator=g), torch.randn(B, Lc, C, generator=g)
+    kw = torch.rand(nkw, generator=g) * 2 if nkw else None
+    k = torch.cat([ks.double(), kc.bfloat16().double()], 1).view(B, Ls + Lc, nh, D).permute(0, 2, 1, 3)
+    v = torch.cat([vs.double(), vc.bfloat16().double()], 1).view(B, Ls + Lc, nh, D).permute(0, 2, 1, 3)
+    qq = q.double().view(B, Lq, nh, D).permute(0, 2, 1, 3)
+    att = ((qq @ k.transpose(-1, -2)) / D ** 0.5).softmax(-1)
+    if nkw:
+        wts = torch.ones(Lq, Ls + Lc, dtype=torch.float64)
+        wts[:, -nkw:] = kw.double()
+        att = att * wts
+    ref = (att @ v).permute(0, 2, 1, 3).reshape(B, Lq, C).float()
+    out = torch.full((B, Lq, C), float("nan"), device=DEV, dtype=torch.bfloat16)
+    qd, ksd, vsd, kcd, vcd = q.to(DEV), ks.to(DEV), vs.to(DEV), kc.to(DEV), vc.to(DEV)
+    kwd = kw.to(DEV) if nkw else None
+    rc = lib.paella_test_attention_bf16(_p(qd), _p(ksd) if Ls else None, _p(vsd) if Ls else None, _p(kcd), _p(vcd), _p(out), B, nh, D, Lq, Ls, Lc, _p(kwd), nkw, _st())
+    assert rc == 0, lib.paella_last_error()
+    torch.cuda.synchronize()
+    err = (out.float().cpu() - ref).abs().max().item()
+    print("bf16 attention core B=%d heads=%d D=%d Lq=%d Lk=%d: max |err| %.2e on outputs of std %.2f" % (B, nh, D, Lq, Ls + Lc, err, ref.std().item()))
+    assert torch.isfinite(out.float()).all() and err <= 1.5e-2
