@@ -150,7 +150,7 @@ def _flip_report(ref, got):
     return flips, (got - ref).abs().max().item(), ref.std().item()
 
 
-@pytest.mark.parametrize("cfg_name,B,grid", [("UNET_MID", 2, 16), ("UNET_570M", 1, 32), ("UNET_570M", 4, 32)])
+@pytest.mark.parametrize("cfg_name,B,grid", [("UNET_MID", 2, 16), ("UNET_570M", 1, 32), ("UNET_570M", 4, 32), ("UNET_MID", 1, 64)])  # (64x64 tokens: 256 queries at level 1 -> the bf16 attention core)
 def test_bf16_forward_deviation_and_restore(built_lib, cfg_name, B, grid):
     cfg = dict(getattr(G, cfg_name))
     m = paella_amd.Paella(**cfg)
@@ -227,7 +227,7 @@ def test_bf16_vqgan_decode_deviation_and_restore(built_lib):
 def test_bf16_attention_core(built_lib, B, nh, D, Lq, Ls, Lc, nkw):
     """attention_bf16_kernel (the fast mode's attention at >= 256 queries): both contractions on bf16 MFMA, softmax in fp32, probabilities rounded to bf16 for the
     second contraction.  Reference: fp64 attention on the bf16-ROUNDED q / k / v (conditioning k / v are rounded by the kernel while staged); what remains is the
-    rounding of the probabilities (2^-9 relative each) and of the output: |err| <= 1.5e-2 on outputs of unit scale."""
+    rounding of the probabilities (2^-9 relative each) and of the output: measured 1.3e-3 ... 2.3e-3 on outputs of std 0.07 ... 0.15; bound 6e-3."""
     lib = built_lib
     g = torch.Generator().manual_seed(Lq * 3 + Lc)
     C = nh * D
@@ -252,4 +252,4 @@ def test_bf16_attention_core(built_lib, B, nh, D, Lq, Ls, Lc, nkw):
     torch.cuda.synchronize()
     err = (out.float().cpu() - ref).abs().max().item()
     print("bf16 attention core B=%d heads=%d D=%d Lq=%d Lk=%d: max |err| %.2e on outputs of std %.2f" % (B, nh, D, Lq, Ls + Lc, err, ref.std().item()))
-    assert torch.isfinite(out.float()).all() and err <= 1.5e-2
+    assert torch.isfinite(out.float()).all() and err <= 6e-3
