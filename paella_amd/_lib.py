@@ -142,7 +142,11 @@ def load():
         fn.restype = res
         fn.argtypes = args
     from ._stamp import source_stamp
-    built, here = lib.paella_source_stamp().decode(), source_stamp()
+    try:
+        here = source_stamp()
+    except OSError as e:  # the kernel sources ship next to the library; without them its provenance cannot be checked
+        raise PaellaHipError("cannot verify %s: the kernel sources it is checked against are missing (%s)" % (LIB_PATH, e)) from e
+    built = lib.paella_source_stamp().decode()
     if built != here:
         raise PaellaHipError("libpaella_hip.so was built from other sources (library stamp %s, sources in the tree %s): rebuild with "
                              "`python -m paella_amd.build`; a stale library is never used silently" % (built, here))

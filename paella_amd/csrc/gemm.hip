@@ -1838,8 +1838,9 @@ static int launch_gemm_cfg_impl(const GemmArgs& g_in, int cfg, int splitk, void*
 // ---------------------------------------------------------------------------
 // head GEMM with the fused sampling tail: one whole tile per workgroup (G = tiles), TAIL instantiations only
 // ---------------------------------------------------------------------------
-// tile of the fused head + tail: 9 = 128x128 (one workgroup per CU: the Philox / log epilogue serialises behind the main loop), 14 = 128x64 8 waves
-// (two or more workgroups per CU overlap epilogue and main loop; twice the per-row partials).  A/B through the test hook only.
+// tile of the fused head + tail: 18 (default) = 64x64 direct-to-LDS, four independent workgroups per CU; 9 = 128x128 (one workgroup per CU: the Philox / log epilogue
+// serialises behind the main loop), 14 = 128x64 on 8 waves (two or more workgroups per CU; twice the per-row partials).  A/B through the test hook only
+// (profiles/r04_head_tail_and_same_box_ab.txt).
 static std::atomic<int> g_tail_tile{18};
 extern "C" int paella_test_gemm_tail_tile(int cfg) {
     if (cfg != 9 && cfg != 14 && cfg != 18) { paella_set_error("fused-tail tile must be 9 (128x128), 14 (128x64) or 18 (64x64, direct-to-LDS)"); return PAELLA_ERR_ARG; }
@@ -1877,7 +1878,7 @@ static int launch_gemm_tail_impl(const GemmArgs& g, hipStream_t st) {
     const unsigned long long T = (unsigned long long)p.tiles_m * p.tiles_n;
     if (T * (unsigned long long)p.KT >= (1ull << 31)) { paella_set_error("gemm_tail: problem too large"); return PAELLA_ERR_ARG; }
     p.U = (unsigned)(T * p.KT);
-    // One whole tile per workgroup.  Measured and NOT kept (profiles/r04_head_tail_ab.txt): 512 persistent workgroups walking T / 512 tiles each (round 3: neutral),
+    // One whole tile per workgroup.  Measured and NOT kept (profiles/r04_head_tail_and_same_box_ab.txt): 512 persistent workgroups walking T / 512 tiles each (round 3: neutral),
     // and the same with the second workgroup of every CU started half a tile period late so that its Philox / log epilogue would run under the other one's main
     // loop (round 4: 20.21 vs 20.21 images/s at configs[2], 112.9-113.3 at batch 32 for every variant) -- the launch is not limited by phase alignment.
     const unsigned long long G = T;
