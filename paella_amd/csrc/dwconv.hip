@@ -101,97 +101,6 @@ __global__ __launch_bounds__(256) void dwconv_ln_block_kernel(const float* __res
     }
 }
 
-// Throughput regime (thousands of positions): ONE WAVE per output position, four positions per workgroup -- the statistics are wave64 shuffles, no LDS, no
-// barriers, and a workgroup's 36 tap rows overlap with its neighbours' in L1 / L2.  Same taps in the same order and the same two-pass LayerNorm as the
-// block kernel; only the order of the cross-lane sums differs (rounding-level).  NV = 16-byte channel slots per lane (C <= 256 * NV).
-template <int NV, bool SKIP>
-__global__ __launch_bounds__(256) void dwconv_ln_wave_kernel(const float* __restrict__ x, const float* __restrict__ skip, const float* __restrict__ w,
-                                                             const float* __restrict__ bias, float* __restrict__ y, unsigned short* __restrict__ y16, int H, int W, int C,
-                                                             float eps, FastDiv dW, FastDiv dH, unsigned total) {
-    const int lane = threadIdx.x & 63;
-    const unsigned pos = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (pos >= total) return;
-    const int C4 = C >> 2;
-    const unsigned prow = fast_div(pos, dW);  // b * H + y
-    const int xx = (int)(pos - prow * (unsigned)W);
-    const int yy = (int)(prow - fast_div(prow, dH) * (unsigned)H);
-    const int64_t img = (int64_t)pos - (int64_t)yy * W - xx;
-    int c4s[NV];
-    bool live[NV];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c4 = lane + i * 64;
-        live[i] = c4 < C4;
-        c4s[i] = live[i] ? c4 : C4 - 1;
-    }
-    f32x4 acc[NV];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) acc[i] = ldq(bias + c4s[i] * 4);
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-        const int sy = yy + ky - 1;
-        const int syc = min(max(sy, 0), H - 1);
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const int sx = xx + kx - 1;
-            const int sxc = min(max(sx, 0), W - 1);
-            const float keep = (sy == syc && sx == sxc) ? 1.0f : 0.0f;  // zero padding
-            const int64_t npos = img + (int64_t)syc * W + sxc;
-            const int tap = ky * 3 + kx;
-#pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                if (!SKIP) {
-                    acc[i] += ldq(x + npos * C + c4s[i] * 4) * (ldq(w + tap * C + c4s[i] * 4) * keep);
-                } else {
-                    const int cc = 8 * c4s[i];
-                    const float* src = cc < C ? (x + npos * C + cc) : (skip + npos * C + (cc - C));
-                    const f32x4 e0 = ldq(src), e1 = ldq(src + 4);
-                    const f32x4 w0 = ldq(w + tap * C + c4s[i] * 4) * keep;
-                    const f32x4 w1 = ldq(w + (9 + tap) * C + c4s[i] * 4) * keep;
-                    acc[i][0] += e0[0] * w0[0] + e0[1] * w1[0];
-                    acc[i][1] += e0[2] * w0[1] + e0[3] * w1[1];
-                    acc[i][2] += e1[0] * w0[2] + e1[1] * w1[2];
-                    acc[i][3] += e1[2] * w0[3] + e1[3] * w1[3];
-                }
-            }
-        }
-    }
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < NV; ++i)
-        if (live[i]) s += (acc[i][0] + acc[i][1]) + (acc[i][2] + acc[i][3]);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    const float mean = s / (float)C;
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < NV; ++i)
-        if (live[i]) {
-            f32x4 d = acc[i] - mean;
-            d = d * d;
-            q += (d[0] + d[1]) + (d[2] + d[3]);
-        }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
-    const float rstd = 1.0f / sqrtf(q / (float)C + eps);
-    if (y16) {
-        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-#pragma unroll
-        for (int i = 0; i < NV; ++i)
-            if (live[i]) *reinterpret_cast<bf16x4*>(y16 + (size_t)pos * C + (lane + i * 64) * 4) = __builtin_convertvector((acc[i] - mean) * rstd, bf16x4);
-    }
-    if (y) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i)
-            if (live[i]) *reinterpret_cast<f32x4*>(y + (size_t)pos * C + (lane + i * 64) * 4) = (acc[i] - mean) * rstd;
-    }
-}
-
-// positions from which the wave-per-position kernel is used (below: the block kernel, whose 256 threads per position keep every tap load of the few
-// positions of a batch-1 grid in flight at once); test hook for A/B: 0 = never
-static int g_dwconv_wave_min = 4096;
-extern "C" int paella_test_dwconv_wave_min(int positions) { g_dwconv_wave_min = positions; return PAELLA_OK; }
-
 int launch_dwconv_ln(const float* x, const float* skip, const float* w, const float* bias, float* y, int B, int H,
                      int W, int C, float eps, hipStream_t st, unsigned short* y16) {
     const int64_t total = (int64_t)B * H * W;
@@ -202,18 +111,6 @@ int launch_dwconv_ln(const float* x, const float* skip, const float* w, const fl
     const int nv = (C / 4 + 255) / 256;
     const dim3 grid((unsigned)total), block(256);
     const FastDiv dW = fast_div_of((unsigned)W), dH = fast_div_of((unsigned)H);
-    if (g_dwconv_wave_min > 0 && total >= g_dwconv_wave_min && C <= 2048 && !skip) {  // (the skip variant holds two activation loads per tap: 250+ registers per lane in this form -- it stays on the block kernel)
-        const dim3 wgrid((unsigned)((total + 3) / 4));
-        const int wnv = (C / 4 + 63) / 64;
-#define DWW(NVv) hipLaunchKernelGGL((dwconv_ln_wave_kernel<NVv, false>), wgrid, block, 0, st, x, skip, w, bias, y, y16, H, W, C, eps, dW, dH, (unsigned)total)
-        if (wnv <= 2) DWW(2);
-        else if (wnv <= 3) DWW(3);
-        else if (wnv <= 5) DWW(5);
-        else DWW(8);
-#undef DWW
-        LAUNCH_CHECK_RET();
-        return PAELLA_OK;
-    }
 #define DW_LAUNCH(NVv)                                                                                                   \
     do {                                                                                                                 \
         if (skip) hipLaunchKernelGGL((dwconv_ln_block_kernel<NVv, true>), grid, block, 0, st, x, skip, w, bias, y, y16, H, W, C, eps, dW, dH); \

@@ -16,8 +16,6 @@ int paella_test_gemm_bf16(const unsigned short* A16, const unsigned short* W16, 
 /* the bf16 attention core of the opt-in fast mode (>= 256 queries in the model): q16 / ks16 / vs16 bf16 [B*L, nhead*D], conditioning k / v fp32, out16 bf16 */
 int paella_test_attention_bf16(const unsigned short* q16, const unsigned short* ks16, const unsigned short* vs16, const float* k_cond, const float* v_cond,
                                unsigned short* out16, int B, int nhead, int D, int Lq, int Lself, int Lcond, const float* key_weights, int n_kw, void* stream);
-/* positions from which the depthwise-conv + LayerNorm runs one wave per position instead of one workgroup per position (default 4096; 0 = never) */
-int paella_test_dwconv_wave_min(int positions);
 /* A/B of the bf16 tile rules: bit 0 = never the 256x128 tile (the fp32 rules' tiles instead) */
 int paella_test_gemm_bf16_rule(int mask);
 /* launches n_launches dependent, nearly empty kernels (blocks x 256 threads touching n_elems floats): boundary floor */

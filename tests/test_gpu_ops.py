@@ -323,30 +323,6 @@ def test_dwconv_ln(lib, B, H, W, C, skip):
     np.testing.assert_allclose(y.cpu().numpy(), ref.numpy(), atol=2e-5, rtol=1e-5)
 
 
-@pytest.mark.parametrize("B,H,W,C", [(2, 8, 8, 32), (1, 16, 16, 640), (3, 5, 7, 1280), (2, 9, 4, 160), (1, 6, 6, 2048)])
-def test_dwconv_ln_wave_per_position_kernel(lib, B, H, W, C):
-    """The throughput-regime form of the ResBlock front half (one wave per position, from 4096 positions up in the product): same taps, same two-pass
-    LayerNorm, here forced through the test hook at small sizes -- against the reference arithmetic and against the block kernel."""
-    g = torch.Generator().manual_seed(B * H + C)
-    x = torch.randn(B, C, H, W, generator=g)
-    w = torch.randn(C, 1, 3, 3, generator=g) * 0.3
-    b = torch.randn(C, generator=g) * 0.1
-    ref = O.ln_channels(F.conv2d(x, w, b, padding=1, groups=C)).permute(0, 2, 3, 1)
-    xn = x.permute(0, 2, 3, 1).contiguous().cuda()
-    wk = w.permute(1, 2, 3, 0).contiguous().cuda()
-    bd = b.cuda()
-    y_block = torch.empty(B, H, W, C, device="cuda")
-    y_wave = torch.full((B, H, W, C), float("nan"), device="cuda")
-    _check(lib, lib.paella_op_dwconv_ln(_p(xn), None, _p(wk), _p(bd), _p(y_block), B, H, W, C, 1e-6, _st()))
-    try:
-        lib.paella_test_dwconv_wave_min(1)
-        _check(lib, lib.paella_op_dwconv_ln(_p(xn), None, _p(wk), _p(bd), _p(y_wave), B, H, W, C, 1e-6, _st()))
-    finally:
-        lib.paella_test_dwconv_wave_min(4096)
-    np.testing.assert_allclose(y_wave.cpu().numpy(), ref.numpy(), atol=2e-5, rtol=1e-5)
-    np.testing.assert_allclose(y_wave.cpu().numpy(), y_block.cpu().numpy(), atol=3e-6, rtol=0)
-
-
 def test_grn_scale(lib):
     B, rows, C = 3, 64, 256
     g = torch.Generator().manual_seed(5)
