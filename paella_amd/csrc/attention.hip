@@ -206,6 +206,8 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
 //   1 = both sub-tiles' S chains of a 32-key stage issued together, alternating accumulators (no two consecutive MFMAs share one; the second chain's results
 //       are in flight while the first sub-tile's softmax runs), PV MFMAs ordered e-outer so that consecutive ones hit different accumulators
 //   2 = variant 1 + s_setprio 1 around the MFMA blocks (a wave in its matrix phase wins issue arbitration against the SIMD's other waves' VALU phases)
+//   5 = ONE online-softmax step per 32-key stage (not bit-identical to the 16-key stepping: same mathematics, one running-maximum update, one rescale of O^T and
+//       one pair of cross-row max reductions per 32 keys instead of two of each): a third less VALU in the phase where the matrix core idles
 //   3 = variant 1 + ONE static priority per workgroup, (blockIdx.x + y + z) % 3: the three waves that share a SIMD come from three workgroups; with distinct
 //       priorities the highest runs its serial chain at full speed and the others fill its VALU phases instead of all three convoying through the matrix core
 template <int DT, int VAR = 1>
@@ -348,6 +350,67 @@ __global__ __launch_bounds__(256) void attention_lds_kernel(AttnArgs args) {
             for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[j][e], qf[j][e], s, 0, 0, 0);
         softmax_pv(key0, s, Vs);
     };
+    // a whole 32-key stage as ONE online-softmax step (VAR 5)
+    auto process32_wide = [&](int key0, const float* Ks, const float* Vs) __attribute__((always_inline)) {
+        f32x4 kf0[DT], kf1[DT];
+        const float* kp = Ks + r16 * PITCH + kq * 4;
+#pragma unroll
+        for (int j = 0; j < DT; ++j) { kf0[j] = *reinterpret_cast<const f32x4*>(kp + j * 16); kf1[j] = *reinterpret_cast<const f32x4*>(kp + 16 * PITCH + j * 16); }
+        f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = s0;
+#pragma unroll
+        for (int j = 0; j < DT; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf0[j][e], qf[j][e], s0, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf1[j][e], qf[j][e], s1, 0, 0, 0);
+            }
+        float vf0[DT][4], vf1[DT][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float* vp = Vs + (kq * 4 + e) * PITCH + r16;
+#pragma unroll
+            for (int j = 0; j < DT; ++j) { vf0[j][e] = vp[j * 16]; vf1[j][e] = vp[16 * PITCH + j * 16]; }
+        }
+        float p[8];
+        float mt = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = key0 + kq * 4 + r;
+            p[r] = key < Lk ? s0[r] * scale : -INFINITY;
+            p[4 + r] = key + 16 < Lk ? s1[r] * scale : -INFINITY;
+            mt = fmaxf(mt, fmaxf(p[r], p[4 + r]));
+        }
+        mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float m_new = fmaxf(m_run, mt);
+        const float alpha = exp_fast(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            p[r] = exp_fast(p[r] - m_new);
+            psum += p[r];
+        }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+        if (key_weights) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int wi = key0 + (r >> 2) * 16 + kq * 4 + (r & 3) - (Lk - n_kw);
+                const float wv = key_weights[min(max(wi, 0), n_kw - 1)];
+                if (wi >= 0 && wi < n_kw) p[r] *= wv;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < DT; ++j) oacc[j] *= alpha;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int j = 0; j < DT; ++j) oacc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf0[j][e], p[e], oacc[j], 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int j = 0; j < DT; ++j) oacc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf1[j][e], p[4 + e], oacc[j], 0, 0, 0);
+    };
     // a whole 32-key stage: both S chains first (two accumulators, alternating), then the two softmax / PV halves in key order
     auto process32 = [&](int key0, const float* Ks, const float* Vs, bool second) __attribute__((always_inline)) {
         f32x4 kf0[DT], kf1[DT];
@@ -382,6 +445,8 @@ __global__ __launch_bounds__(256) void attention_lds_kernel(AttnArgs args) {
             for (int sub = 0; sub < KTILE / 16; ++sub)
                 if (kt * KTILE + sub * 16 < Lk)  // workgroup-uniform: skip a fully masked half tile
                     process16(kt * KTILE + sub * 16, Ks + sub * 16 * PITCH, Vs + sub * 16 * PITCH);
+        } else if constexpr (VAR == 5) {
+            process32_wide(kt * KTILE, Ks, Vs);  // (masked keys get probability 0: a ragged last stage needs no branch)
         } else {
             process32(kt * KTILE, Ks, Vs, kt * KTILE + 16 < Lk);  // (a fully masked second half is multiplied -- clamped rows -- and dropped)
         }
@@ -605,10 +670,11 @@ int launch_attention(const AttnArgs& a, hipStream_t st) {
         else hipLaunchKernelGGL((attention_kernel<n, false>), grid, dim3(256), 0, st, a);                  \
         break;
     const int variant = g_attn_variant.load();
-    if (lds && a.D == 80 && variant >= 10 && variant <= 13) {
+    if (lds && a.D == 80 && variant >= 10 && variant <= 15 && variant != 14) {
         if (variant == 10) hipLaunchKernelGGL((attention_lds_kernel<5, 0>), grid, dim3(256), 0, st, a);
         else if (variant == 11) hipLaunchKernelGGL((attention_lds_kernel<5, 1>), grid, dim3(256), 0, st, a);
         else if (variant == 12) hipLaunchKernelGGL((attention_lds_kernel<5, 2>), grid, dim3(256), 0, st, a);
+        else if (variant == 15) hipLaunchKernelGGL((attention_lds_kernel<5, 5>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((attention_lds_kernel<5, 3>), grid, dim3(256), 0, st, a);
         LAUNCH_CHECK_RET();
         return PAELLA_OK;
