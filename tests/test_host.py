@@ -112,3 +112,22 @@ def test_bench_traffic_files_are_stamped_and_stale_ones_refused(monkeypatch):
     assert val is None and "stale" in note and "refused" in note
     val, note = bench.load_traffic("570m", 7, 32, 8)  # a workload nobody profiled
     assert val is None
+
+
+def test_gemm_precision_is_a_per_model_switch_with_no_process_wide_state():
+    """The opt-in bf16 fast mode is selected per model object and validated on the host; the package exposes no process-wide setter, and
+    the library exports none (include/paella_hip.h: paella_unet_set_precision / paella_vqgan_set_precision take a model handle)."""
+    import pytest
+    import paella_amd
+    from paella_amd import _lib
+    a, b = paella_amd.Paella(**G.UNET_TINY), paella_amd.Paella(**G.UNET_TINY)
+    assert a.get_gemm_precision() == b.get_gemm_precision() == "fp32"
+    assert a.set_gemm_precision("bf16") is a and a.get_gemm_precision() == "bf16" and b.get_gemm_precision() == "fp32"
+    a.set_gemm_precision("fp32")
+    with pytest.raises(ValueError):
+        a.set_gemm_precision("fp16")
+    v = paella_amd.VQModel(**G.VQ_TINY_F8)
+    assert v.set_gemm_precision("bf16").get_gemm_precision() == "bf16"
+    assert not hasattr(paella_amd, "set_gemm_precision")
+    assert not any("gemm_precision" in n for n in list(_lib.SIGNATURES) + list(_lib.TEST_HOOKS))
+    assert "paella_unet_set_precision" in _lib.SIGNATURES and "paella_vqgan_set_precision" in _lib.SIGNATURES
