@@ -193,26 +193,29 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
 // ---------------------------------------------------------------------------------------------------------------------------------
 // Large query counts (>= 256 queries per sample: 512 px grids and up, BASELINE configs 3-5 where attention is up to ~40 % of a
 // block's FLOPs): one workgroup = 64 queries of one (sample, head); its 4 waves own 16 queries each and SHARE the K/V tiles, which
-// are fetched from global memory ONCE per workgroup with coalesced 16-byte loads and staged in LDS (32 keys per stage, two stages,
-// register-prefetched: the loads of tile t+1 fly while tile t multiplies).
-//   K tile  [32][D + 4]: the K.Q^T fragment of a lane is 16 contiguous bytes of one key row -> ds_read_b128; the row pitch of
-//           D/4 + 1 (odd) 16-byte slots puts the 16 rows of a lane group on 16 different slots: conflict-free.
-//   V tile  [32][D + 4]: the V^T.P^T fragment of a lane is V[key = 4*kq + e][d = 16*j + r16] -> ds_read_b32; lanes r16 sweep 16
-//           consecutive banks and 4*(D + 4) mod 32 = 16 puts kq = 0 / 1 on disjoint halves: conflict-free.
-// Same arithmetic in the same order as the register-fed kernel above (16-key steps walked in key order per wave): results are
-// bit-identical to it.
+// are fetched from global memory ONCE per workgroup and staged in LDS (32 keys per stage, two stages: tile t+1 lands while tile t multiplies).
+// Per 32-key stage a wave issues both sub-tiles' S chains together (two accumulators, alternating: no two consecutive MFMAs share one; the second chain's
+// results are in flight while the first sub-tile's softmax runs), then the two online-softmax / PV halves in key order with the PV MFMAs ordered so that
+// consecutive ones hit different accumulators.  Same arithmetic in the same order as the register-fed kernel above (16-key steps walked in key order per
+// wave): results are bit-identical to it, whatever the staging.
+//
+// STAGING (template parameter STG).  The round-5 ablations (profiles/r05_attention_staging_probe.txt) put the kernel's idle matrix-core time on the staging, not on
+// the softmax: with no softmax at all 0.73 -> 0.77 of peak, with no staging and no barrier in the loop 0.73 -> 0.84 (both: 0.90).
+//   0 = through registers (rounds 2-5; kept behind the test hook for A/B): per stage and thread 6 global b128 loads with their clamp / select / divide address
+//       arithmetic, 6 ds_write_b128 (13 issue cycles each), 24 staging VGPRs.
+//   1 = direct-to-LDS buffer loads: one wave instruction lands 64 consecutive 16-byte chunks, so a tile is [32 rows][D/4 + 1 chunks] (the pad chunk of a row is a
+//       duplicate of its last chunk) rounded up to whole wave instructions; a stage whose 32 keys are all self rows or all conditioning rows (every stage but at
+//       most two) addresses with per-lane offsets computed ONCE plus one scalar offset per stage; the mixed stages clamp and select per lane.  No staging
+//       registers, no ds_write: 138 -> 110 VGPRs at head_dim 80 and 0.70-0.72 -> 0.77-0.80 of the fp32 MFMA peak.
+//       K tile: the K.Q^T fragment of a lane is 16 contiguous bytes of one key row -> ds_read_b128; row pitch D/4 + 1 (odd) 16-byte slots.
+//       V tile: the V^T.P^T fragment of a lane is V[key = 4*kq + e][d = 16*j + r16] -> ds_read_b32; lanes r16 sweep 16 consecutive banks and
+//       4*(D + 4) mod 32 = 16 puts kq = 0 / 1 on disjoint halves: conflict-free.
+//   2 = STG 1 without any padding (odd D/16 only): a tile is exactly [32][D] floats = 10 wave instructions at head_dim 80 and a workgroup's two stages are
+//       40 960 B, so FOUR workgroups fit the CU's 160 KB (4 waves per SIMD instead of 3).  Bank conflicts are avoided by WHERE the DMA puts things, which costs
+//       nothing (the source address of a lane is free):  K tile: LDS chunk position p of row r holds source chunk p ^ f((r >> 2) & 3), f = {0, 3, 2, 1} (an XOR on
+//       the low two bits stays inside the row's D/4 chunks); every ds_read_b128 lane group then covers 16 distinct 16-byte slots.  V tile: LDS row r holds key
+//       r ^ ((r >> 2) & 1), so the rows the kq = 0 / 1 (2 / 3) lanes of a ds_read_b32 group read have opposite parity = disjoint 16-bank halves.
 // ---------------------------------------------------------------------------------------------------------------------------------
-// VAR (A/B through the test hook; the arithmetic per query is the same in every variant -> bit-identical outputs):
-//   0 = one 16-key sub-tile at a time: K fragments -> 20 DEPENDENT S MFMAs -> softmax -> 5 x 4 dependent PV MFMAs (rounds 2-4)
-//   1 = both sub-tiles' S chains of a 32-key stage issued together, alternating accumulators (no two consecutive MFMAs share one; the second chain's results
-//       are in flight while the first sub-tile's softmax runs), PV MFMAs ordered e-outer so that consecutive ones hit different accumulators
-//   2 = variant 1 + s_setprio 1 around the MFMA blocks (a wave in its matrix phase wins issue arbitration against the SIMD's other waves' VALU phases)
-//   5 = ONE online-softmax step per 32-key stage (not bit-identical to the 16-key stepping: same mathematics, one running-maximum update, one rescale of O^T and
-//       one pair of cross-row max reductions per 32 keys instead of two of each): a third less VALU in the phase where the matrix core idles
-//   6 = variant 5 in the base-2 domain: Q is pre-multiplied by scale * log2(e) once per workgroup, so a score IS the exponent (no multiply per score, no multiply
-//       inside exp), and only the ragged last stage carries key masks (full stages run a mask-free instantiation of the step)
-//   3 = variant 1 + ONE static priority per workgroup, (blockIdx.x + y + z) % 3: the three waves that share a SIMD come from three workgroups; with distinct
-//       priorities the highest runs its serial chain at full speed and the others fill its VALU phases instead of all three convoying through the matrix core
 __device__ __forceinline__ void attn_dma16(__amdgpu_buffer_rsrc_t rsrc, float* lds_wave_base, unsigned voffset, int soffset) {
 #if defined(__HIP_DEVICE_COMPILE__)
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voffset, soffset, 0, 0);
@@ -221,22 +224,19 @@ __device__ __forceinline__ void attn_dma16(__amdgpu_buffer_rsrc_t rsrc, float* l
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t attn_rsrc(const float* p, size_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)(bytes > 0x7fffffffull ? 0x7fffffffull : bytes), 0x00020000);
 }
-// STG 1: the K / V tiles reach LDS by direct-to-LDS buffer loads (no staging registers, no ds_write, per-stage address arithmetic reduced to one scalar offset):
-//   one wave instruction lands 64 consecutive 16-byte chunks, so a tile is [32 rows][D/4 + 1 chunks] (the same PITCH = D + 4 floats; the pad chunk of a row is a
-//   duplicate of its last chunk) rounded up to a whole number of wave instructions; a stage whose 32 keys are all self rows or all conditioning rows (every stage but
-//   at most two) addresses with per-lane offsets computed ONCE and a per-stage scalar offset; the mixed stages select per lane.
-template <int DT, int VAR = 1, int ABL = 0, int STG = 0>  // ABL: timing ablations of VAR 5 (WRONG results; probe only): 1 = no softmax, 2 = no staging / barriers in the loop, 3 = both
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void attention_lds_kernel(AttnArgs args) {
+template <int DT, int STG>
+__global__ __launch_bounds__(256) void attention_lds_kernel(AttnArgs args) {
     constexpr int D = DT * 16, D4 = D / 4;
-    constexpr int KTILE = 32;                 // keys per LDS stage
-    constexpr int PITCH = D + 4;              // floats per LDS row
-    constexpr int RCH = D4 + 1;               // 16-byte chunks per LDS row
-    constexpr int NI = (KTILE * RCH + 63) / 64;   // STG 1: wave instructions per tile
-    constexpr int NPW = (NI + 3) / 4;             // ... per wave and tensor
+    constexpr int KTILE = 32;                          // keys per LDS stage
+    constexpr int PITCH = STG == 2 ? D : D + 4;        // floats per LDS row
+    constexpr int RCH = PITCH / 4;                     // 16-byte chunks per LDS row
+    constexpr int NI = (KTILE * RCH + 63) / 64;        // direct-to-LDS: wave instructions per tile
+    constexpr int NPW = (NI + 3) / 4;                  // ... per wave and tensor
     constexpr int VT_OFF = STG ? NI * 256 : KTILE * PITCH;  // V tile offset inside a stage (floats)
-    constexpr int STAGE = 2 * VT_OFF;         // K tile + V tile
-    constexpr int NITEM = KTILE * D4;         // float4 items per tensor per stage
+    constexpr int STAGE = 2 * VT_OFF;                  // K tile + V tile
+    constexpr int NITEM = KTILE * D4;                  // register staging: float4 items per tensor per stage
     constexpr int NL = STG ? 1 : (NITEM + 255) / 256;
+    static_assert(STG != 2 || (DT & 1), "the unpadded layout's swizzle needs an odd number of 64-byte blocks per row");
     __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
 
     // scalar copies of the argument fields: lambdas that capture the argument STRUCT by reference make hipcc spill it to scratch
@@ -252,11 +252,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void a
     const int r16 = lane & 15, kq = lane >> 4;
     const int Lk = Lself + Lcond;
     const int ntiles = (Lk + KTILE - 1) / KTILE;
-    if constexpr (VAR == 3) {
-        const unsigned pr = (blockIdx.x + blockIdx.y + blockIdx.z) % 3u;
-        if (pr == 2) __builtin_amdgcn_s_setprio(2);
-        else if (pr == 1) __builtin_amdgcn_s_setprio(1);
-    }
 
     f32x4 qf[DT];
     {
@@ -265,19 +260,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void a
 #pragma unroll
         for (int j = 0; j < DT; ++j) qf[j] = *reinterpret_cast<const f32x4*>(qp + j * 16);
     }
-    if constexpr (VAR == 6) {
-        const float qs = scale * 1.44269504088896340736f;
-#pragma unroll
-        for (int j = 0; j < DT; ++j) qf[j] *= qs;
-    }
     const float* ks_base = Lself ? args.k_self + (size_t)b * Lself * ld_self + h * D : nullptr;
     const float* vs_base = Lself ? args.v_self + (size_t)b * Lself * ld_self + h * D : nullptr;
     const float* kc_base = Lcond ? args.k_cond + (size_t)b * Lcond * ld_cond + h * D : nullptr;
     const float* vc_base = Lcond ? args.v_cond + (size_t)b * Lcond * ld_cond + h * D : nullptr;
 
-    // staging: item = (key, c4) of the K tile and the same item of the V tile; loads are unconditional from clamped rows (masked
-    // keys get score -inf below).  K and V go through separate, fully unrolled loops: a run-time K/V selector makes hipcc build a
-    // pointer table in scratch.
+    // ---- STG 0: item = (key, c4) of the K tile and the same item of the V tile; loads are unconditional from clamped rows (masked keys get score -inf below).
+    // K and V go through separate, fully unrolled loops: a run-time K/V selector makes hipcc build a pointer table in scratch.
     f32x4 stk[NL], stv[NL];
     auto load_tile = [&](int kt) __attribute__((always_inline)) {
 #pragma unroll
@@ -299,23 +288,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void a
             if (NL * 256 == NITEM || idx < NITEM) {
                 const int key_in = idx / D4, c4 = idx - key_in * D4;
                 *reinterpret_cast<f32x4*>(base + key_in * PITCH + c4 * 4) = stk[i];
-                *reinterpret_cast<f32x4*>(base + KTILE * PITCH + key_in * PITCH + c4 * 4) = stv[i];
+                *reinterpret_cast<f32x4*>(base + VT_OFF + key_in * PITCH + c4 * 4) = stv[i];
             }
         }
     };
-    // STG 1: direct-to-LDS staging.  Wave w issues instructions m = 4 i + w (i < NPW, m < NI) of the K tile and the same of the V tile; lane l of instruction m
-    // lands chunk g = 64 m + l = (row g / RCH, chunk g % RCH) of the tile (rows past 31: the tile's rounding, a re-load of row 31 into unused LDS).
-    unsigned dv_self[NPW], dv_cond[NPW];
-    int drow[NPW];
+    // ---- STG 1 / 2: wave w issues instructions m = 4 i + w (i < NPW, m < NI) of the K tile and the same of the V tile; lane l of instruction m lands LDS chunk
+    // g = 64 m + l = (row g / RCH, position g % RCH) of the tile (rows past 31: the tile's rounding, a re-load of row 31 into unused LDS).
+    // krow / vrow: the key row (0..31) the chunk comes from; kcb / vcb: its byte offset inside that row.
+    int krow[NPW], vrow[NPW];
+    unsigned kcb[NPW], vcb[NPW];
     __amdgpu_buffer_rsrc_t rs_ks, rs_vs, rs_kc, rs_vc;
-    if constexpr (STG) {
+    if constexpr (STG != 0) {
 #pragma unroll
         for (int i = 0; i < NPW; ++i) {
             const int g = (4 * i + wave) * 64 + lane;
-            const int row = min(g / RCH, KTILE - 1), c = min(g - (g / RCH) * RCH, D4 - 1);
-            drow[i] = row;
-            dv_self[i] = (unsigned)(row * ld_self * 4 + c * 16);
-            dv_cond[i] = (unsigned)(row * ld_cond * 4 + c * 16);
+            const int row = min(g / RCH, KTILE - 1), pos = min(g - (g / RCH) * RCH, D4 - 1);
+            if constexpr (STG == 2) {
+                krow[i] = row;
+                kcb[i] = (unsigned)((pos ^ ((4 - ((row >> 2) & 3)) & 3)) * 16);  // f = {0, 3, 2, 1}
+                vrow[i] = row ^ ((row >> 2) & 1);
+                vcb[i] = (unsigned)(pos * 16);
+            } else {
+                krow[i] = vrow[i] = row;
+                kcb[i] = vcb[i] = (unsigned)(pos * 16);
+            }
         }
         const size_t self_bytes = (size_t)max(Lself, 1) * ld_self * 4, cond_bytes = (size_t)max(Lcond, 1) * ld_cond * 4;
         rs_ks = attn_rsrc(Lself ? ks_base : kc_base, self_bytes);
@@ -331,36 +327,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void a
 #pragma unroll
             for (int i = 0; i < NPW; ++i)
                 if (4 * i + wave < NI) {
-                    attn_dma16(rs_ks, base + (4 * i + wave) * 256, dv_self[i], so);
-                    attn_dma16(rs_vs, base + VT_OFF + (4 * i + wave) * 256, dv_self[i], so);
+                    attn_dma16(rs_ks, base + (4 * i + wave) * 256, (unsigned)(krow[i] * ld_self * 4) + kcb[i], so);
+                    attn_dma16(rs_vs, base + VT_OFF + (4 * i + wave) * 256, (unsigned)(vrow[i] * ld_self * 4) + vcb[i], so);
                 }
         } else if (kb >= Lself && kb + KTILE <= Lk) {  // 32 conditioning rows
             const int so = (kb - Lself) * ld_cond * 4;
 #pragma unroll
             for (int i = 0; i < NPW; ++i)
                 if (4 * i + wave < NI) {
-                    attn_dma16(rs_kc, base + (4 * i + wave) * 256, dv_cond[i], so);
-                    attn_dma16(rs_vc, base + VT_OFF + (4 * i + wave) * 256, dv_cond[i], so);
+                    attn_dma16(rs_kc, base + (4 * i + wave) * 256, (unsigned)(krow[i] * ld_cond * 4) + kcb[i], so);
+                    attn_dma16(rs_vc, base + VT_OFF + (4 * i + wave) * 256, (unsigned)(vrow[i] * ld_cond * 4) + vcb[i], so);
                 }
         } else {  // the self / conditioning boundary or the ragged last stage: clamp and select per lane (masked keys get score -inf below)
 #pragma unroll
             for (int i = 0; i < NPW; ++i)
                 if (4 * i + wave < NI) {
-                    const int key = min(kb + drow[i], Lk - 1);
-                    const unsigned cb = dv_self[i] - (unsigned)(drow[i] * ld_self * 4);  // the chunk's byte offset inside its row
                     float* dk = base + (4 * i + wave) * 256;
-                    if (key < Lself) {
-                        const unsigned vo = (unsigned)(key * ld_self * 4) + cb;
-                        attn_dma16(rs_ks, dk, vo, 0);
-                        attn_dma16(rs_vs, dk + VT_OFF, vo, 0);
-                    } else {
-                        const unsigned vo = (unsigned)((key - Lself) * ld_cond * 4) + cb;
-                        attn_dma16(rs_kc, dk, vo, 0);
-                        attn_dma16(rs_vc, dk + VT_OFF, vo, 0);
-                    }
+                    const int kk = min(kb + krow[i], Lk - 1), kv = min(kb + vrow[i], Lk - 1);
+                    if (kk < Lself) attn_dma16(rs_ks, dk, (unsigned)(kk * ld_self * 4) + kcb[i], 0);
+                    else attn_dma16(rs_kc, dk, (unsigned)((kk - Lself) * ld_cond * 4) + kcb[i], 0);
+                    if (kv < Lself) attn_dma16(rs_vs, dk + VT_OFF, (unsigned)(kv * ld_self * 4) + vcb[i], 0);
+                    else attn_dma16(rs_vc, dk + VT_OFF, (unsigned)((kv - Lself) * ld_cond * 4) + vcb[i], 0);
                 }
         }
     };
+    // fragment addresses inside a tile (floats): K row r16 (+16), this lane's 16-byte chunk kq (+4 j); V row 4 kq + e (+16), column r16 (+16 j)
+    const int kfrag = STG == 2 ? r16 * PITCH + ((kq ^ ((4 - ((r16 >> 2) & 3)) & 3)) * 4) : r16 * PITCH + kq * 4;
+    auto vfrag = [&](int e) __attribute__((always_inline)) { return (STG == 2 ? ((kq * 4 + e) ^ (kq & 1)) : kq * 4 + e) * PITCH + r16; };
 
     f32x4 oacc[DT];
 #pragma unroll
@@ -372,7 +365,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void a
         float vf[DT][4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float* vp = Vs + (kq * 4 + e) * PITCH + r16;
+            const float* vp = Vs + vfrag(e);
 #pragma unroll
             for (int j = 0; j < DT; ++j) vf[j][e] = vp[j * 16];
         }
@@ -406,165 +399,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void a
         }
 #pragma unroll
         for (int j = 0; j < DT; ++j) oacc[j] *= alpha;
-        if (VAR == 2) __builtin_amdgcn_s_setprio(1);
-        if (VAR == 0) {
-#pragma unroll
-            for (int j = 0; j < DT; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) oacc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[j][e], p[e], oacc[j], 0, 0, 0);
-        } else {  // same four accumulations per oacc[j] in the same order (e = 0..3); consecutive MFMAs hit different accumulators
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int j = 0; j < DT; ++j) oacc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[j][e], p[e], oacc[j], 0, 0, 0);
-        }
-        if (VAR == 2) __builtin_amdgcn_s_setprio(0);
-    };
-    auto process16 = [&](int key0, const float* Ks, const float* Vs) __attribute__((always_inline)) {  // 16 keys starting at key0; Ks / Vs = this sub-tile's rows
-        f32x4 kf[DT];
-        const float* kp = Ks + r16 * PITCH + kq * 4;
-#pragma unroll
-        for (int j = 0; j < DT; ++j) kf[j] = *reinterpret_cast<const f32x4*>(kp + j * 16);
-        f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < DT; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[j][e], qf[j][e], s, 0, 0, 0);
-        softmax_pv(key0, s, Vs);
-    };
-    // a whole 32-key stage as ONE online-softmax step (VAR 5)
-    auto process32_wide = [&](int key0, const float* Ks, const float* Vs) __attribute__((always_inline)) {
-        f32x4 kf0[DT], kf1[DT];
-        const float* kp = Ks + r16 * PITCH + kq * 4;
-#pragma unroll
-        for (int j = 0; j < DT; ++j) { kf0[j] = *reinterpret_cast<const f32x4*>(kp + j * 16); kf1[j] = *reinterpret_cast<const f32x4*>(kp + 16 * PITCH + j * 16); }
-        f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = s0;
-#pragma unroll
-        for (int j = 0; j < DT; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf0[j][e], qf[j][e], s0, 0, 0, 0);
-                s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf1[j][e], qf[j][e], s1, 0, 0, 0);
-            }
-        float vf0[DT][4], vf1[DT][4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float* vp = Vs + (kq * 4 + e) * PITCH + r16;
-#pragma unroll
-            for (int j = 0; j < DT; ++j) { vf0[j][e] = vp[j * 16]; vf1[j][e] = vp[16 * PITCH + j * 16]; }
-        }
-        float p[8];
-        float mt = -INFINITY;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int key = key0 + kq * 4 + r;
-            p[r] = key < Lk ? s0[r] * scale : -INFINITY;
-            p[4 + r] = key + 16 < Lk ? s1[r] * scale : -INFINITY;
-            mt = fmaxf(mt, fmaxf(p[r], p[4 + r]));
-        }
-        float alpha = 1.0f;
-        if constexpr ((ABL & 1) == 0) {
-        mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
-        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-        const float m_new = fmaxf(m_run, mt);
-        alpha = exp_fast(m_run - m_new);
-        float psum = 0.f;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            p[r] = exp_fast(p[r] - m_new);
-            psum += p[r];
-        }
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
-        } else { l_run = 1.0f; }
-        if (key_weights && (ABL & 1) == 0) {
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const int wi = key0 + (r >> 2) * 16 + kq * 4 + (r & 3) - (Lk - n_kw);
-                const float wv = key_weights[min(max(wi, 0), n_kw - 1)];
-                if (wi >= 0 && wi < n_kw) p[r] *= wv;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < DT; ++j) oacc[j] *= alpha;
+        // the four accumulations per oacc[j] in the order e = 0..3; consecutive MFMAs hit different accumulators
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int j = 0; j < DT; ++j) oacc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf0[j][e], p[e], oacc[j], 0, 0, 0);
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int j = 0; j < DT; ++j) oacc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf1[j][e], p[4 + e], oacc[j], 0, 0, 0);
-    };
-    // VAR 6: the same step with base-2 exponents (Q pre-scaled) and compile-time key masking
-    auto process32_log2 = [&](int key0, const float* Ks, const float* Vs, auto masked_tag) __attribute__((always_inline)) {
-        constexpr bool MASKED = decltype(masked_tag)::value;
-        f32x4 kf0[DT], kf1[DT];
-        const float* kp = Ks + r16 * PITCH + kq * 4;
-#pragma unroll
-        for (int j = 0; j < DT; ++j) { kf0[j] = *reinterpret_cast<const f32x4*>(kp + j * 16); kf1[j] = *reinterpret_cast<const f32x4*>(kp + 16 * PITCH + j * 16); }
-        f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = s0;
-#pragma unroll
-        for (int j = 0; j < DT; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf0[j][e], qf[j][e], s0, 0, 0, 0);
-                s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf1[j][e], qf[j][e], s1, 0, 0, 0);
-            }
-        float vf0[DT][4], vf1[DT][4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float* vp = Vs + (kq * 4 + e) * PITCH + r16;
-#pragma unroll
-            for (int j = 0; j < DT; ++j) { vf0[j][e] = vp[j * 16]; vf1[j][e] = vp[16 * PITCH + j * 16]; }
-        }
-        float p[8];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int key = key0 + kq * 4 + r;
-            p[r] = (!MASKED || key < Lk) ? s0[r] : -INFINITY;
-            p[4 + r] = (!MASKED || key + 16 < Lk) ? s1[r] : -INFINITY;
-        }
-        float mt = fmaxf(fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3])), fmaxf(fmaxf(p[4], p[5]), fmaxf(p[6], p[7])));
-        mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
-        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-        const float m_new = fmaxf(m_run, mt);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        float psum = 0.f;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            p[r] = __builtin_amdgcn_exp2f(p[r] - m_new);
-            psum += p[r];
-        }
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
-        if (key_weights) {
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const int wi = key0 + (r >> 2) * 16 + kq * 4 + (r & 3) - (Lk - n_kw);
-                const float wv = key_weights[min(max(wi, 0), n_kw - 1)];
-                if (wi >= 0 && wi < n_kw) p[r] *= wv;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < DT; ++j) oacc[j] *= alpha;
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int j = 0; j < DT; ++j) oacc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf0[j][e], p[e], oacc[j], 0, 0, 0);
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int j = 0; j < DT; ++j) oacc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf1[j][e], p[4 + e], oacc[j], 0, 0, 0);
+            for (int j = 0; j < DT; ++j) oacc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[j][e], p[e], oacc[j], 0, 0, 0);
     };
     // a whole 32-key stage: both S chains first (two accumulators, alternating), then the two softmax / PV halves in key order
     auto process32 = [&](int key0, const float* Ks, const float* Vs, bool second) __attribute__((always_inline)) {
         f32x4 kf0[DT], kf1[DT];
-        const float* kp = Ks + r16 * PITCH + kq * 4;
+        const float* kp = Ks + kfrag;
 #pragma unroll
         for (int j = 0; j < DT; ++j) { kf0[j] = *reinterpret_cast<const f32x4*>(kp + j * 16); kf1[j] = *reinterpret_cast<const f32x4*>(kp + 16 * PITCH + j * 16); }
         f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = s0;
-        if (VAR == 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int j = 0; j < DT; ++j)
 #pragma unroll
@@ -572,12 +419,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void a
                 s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf0[j][e], qf[j][e], s0, 0, 0, 0);
                 s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf1[j][e], qf[j][e], s1, 0, 0, 0);
             }
-        if (VAR == 2) __builtin_amdgcn_s_setprio(0);
         softmax_pv(key0, s0, Vs);
         if (second) softmax_pv(key0 + 16, s1, Vs + 16 * PITCH);
     };
 
-    if constexpr (STG) {
+    if constexpr (STG != 0) {
         dma_stage(0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
@@ -586,217 +432,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void a
     }
     __syncthreads();
     for (int kt = 0; kt < ntiles; ++kt) {
-        const int slot = (ABL & 2) ? 0 : (kt & 1);
-        if constexpr (STG) {
+        const int slot = kt & 1;
+        if constexpr (STG != 0) {
             if (kt + 1 < ntiles) dma_stage(kt + 1, slot ^ 1);  // lands while this stage computes; slot ^ 1 was released by the barrier that ended stage kt - 1
-        } else if constexpr ((ABL & 2) == 0) {
+        } else {
             load_tile(min(kt + 1, ntiles - 1));  // the last iteration re-reads its own tile (L1/L2 hit, never consumed)
         }
         __builtin_amdgcn_sched_barrier(0);
         const float* Ks = smem + slot * STAGE;
-        const float* Vs = Ks + VT_OFF;
-        if constexpr (VAR == 0) {
-#pragma unroll
-            for (int sub = 0; sub < KTILE / 16; ++sub)
-                if (kt * KTILE + sub * 16 < Lk)  // workgroup-uniform: skip a fully masked half tile
-                    process16(kt * KTILE + sub * 16, Ks + sub * 16 * PITCH, Vs + sub * 16 * PITCH);
-        } else if constexpr (VAR == 6) {
-            if ((kt + 1) * KTILE <= Lk) process32_log2(kt * KTILE, Ks, Vs, std::false_type{});
-            else process32_log2(kt * KTILE, Ks, Vs, std::true_type{});
-        } else if constexpr (VAR == 5) {
-            process32_wide(kt * KTILE, Ks, Vs);  // (masked keys get probability 0: a ragged last stage needs no branch)
-        } else {
-            process32(kt * KTILE, Ks, Vs, kt * KTILE + 16 < Lk);  // (a fully masked second half is multiplied -- clamped rows -- and dropped)
-        }
+        process32(kt * KTILE, Ks, Ks + VT_OFF, kt * KTILE + 16 < Lk);  // (a fully masked second half is multiplied -- clamped rows -- and dropped)
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (STG) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's part of the next stage has landed before the barrier that publishes it
-            __syncthreads();
-        } else if constexpr ((ABL & 2) == 0) {
-            store_tile(slot ^ 1);
-            __syncthreads();
-        }
-    }
-    float l = l_run;
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
-    const float inv = 1.0f / l;
-    const int q = q0 + r16;
-    if (q < Lq) {
-        const size_t oo = ((size_t)b * Lq + q) * ldo + h * D + kq * 4;
-        unsigned short* const o16 = args.out16;
-#pragma unroll
-        for (int j = 0; j < DT; ++j) {
-            if (o16) *reinterpret_cast<bf16x4*>(o16 + oo + j * 16) = __builtin_convertvector(oacc[j] * inv, bf16x4);
-            else *reinterpret_cast<f32x4*>(args.out + oo + j * 16) = oacc[j] * inv;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------------
-// In-wave software pipeline of the LDS-staged kernel: the scores of stage t+1 are contracted while the softmax of stage t runs.
-// attention_lds_kernel leaves the matrix core idle whenever the waves that share a SIMD are all in their softmax (its 40 S MFMAs, its VALU
-// phase and its 40 PV MFMAs are three serial blocks, and nothing in ONE wave overlaps); here the instruction stream of every wave itself
-// holds independent MFMA and VALU work side by side:
-//   stage t:   S(t+1) = K(t+1) . Q^T   (40 MFMAs)   ||   softmax of S(t) (the VALU phase)      -> then rescale O^T, then O^T += V(t)^T . P(t)^T (40 MFMAs)
-// K therefore runs one stage ahead of V in LDS (K slots hold stages t+1 / t+2, V slots t / t+1: the same 4 tiles as the unpipelined kernel).
-// One online-softmax step per 32 keys in the base-2 domain (Q pre-multiplied by scale * log2 e: a score IS the exponent); masked keys get
-// probability 0 by select, so the loop body is ONE basic block and the scheduler can interleave the two streams.
-// ---------------------------------------------------------------------------------------------------------------------------------
-template <int DT, bool KW>
-__global__ __launch_bounds__(256) void attention_pipe_kernel(AttnArgs args) {
-    constexpr int D = DT * 16, D4 = D / 4;
-    constexpr int KTILE = 32;
-    constexpr int PITCH = D + 4;
-    constexpr int TILE = KTILE * PITCH;
-    constexpr int NITEM = KTILE * D4;
-    constexpr int NL = (NITEM + 255) / 256;
-    __shared__ __attribute__((aligned(16))) float smem[4 * TILE];  // K slot 0, K slot 1, V slot 0, V slot 1
-
-    const int Lq = args.Lq, Lself = args.Lself, Lcond = args.Lcond, ld_self = args.ld_self, ld_cond = args.ld_cond, ldq = args.ldq, ldo = args.ldo;
-    const int n_kw = args.n_kw;
-    const float* const key_weights = args.key_weights;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int q0 = (blockIdx.x * 4 + wave) * 16;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int r16 = lane & 15, kq = lane >> 4;
-    const int Lk = Lself + Lcond;
-    const int ntiles = (Lk + KTILE - 1) / KTILE;
-
-    f32x4 qf[DT];
-    {
-        const int q = min(q0 + r16, Lq - 1);
-        const float* qp = args.q + ((size_t)b * Lq + q) * ldq + h * D + kq * 4;
-        const float qs = args.scale * 1.44269504088896340736f;
-#pragma unroll
-        for (int j = 0; j < DT; ++j) qf[j] = *reinterpret_cast<const f32x4*>(qp + j * 16) * qs;
-    }
-    const float* ks_base = Lself ? args.k_self + (size_t)b * Lself * ld_self + h * D : nullptr;
-    const float* vs_base = Lself ? args.v_self + (size_t)b * Lself * ld_self + h * D : nullptr;
-    const float* kc_base = Lcond ? args.k_cond + (size_t)b * Lcond * ld_cond + h * D : nullptr;
-    const float* vc_base = Lcond ? args.v_cond + (size_t)b * Lcond * ld_cond + h * D : nullptr;
-
-    f32x4 stk[NL], stv[NL];
-    auto load_rows = [&](int kt, f32x4 (&st)[NL], const float* self_base, const float* cond_base) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < NL; ++i) {
-            const int idx = min(tid + i * 256, NITEM - 1);
-            const int key_in = idx / D4, c4 = idx - key_in * D4;
-            const int key = min(kt * KTILE + key_in, Lk - 1);
-            const bool self = key < Lself;
-            const size_t off = self ? (size_t)key * ld_self : (size_t)(key - Lself) * ld_cond;
-            st[i] = *reinterpret_cast<const f32x4*>((self ? self_base : cond_base) + off + c4 * 4);
-        }
-    };
-    auto store_rows = [&](float* base, const f32x4 (&st)[NL]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < NL; ++i) {
-            const int idx = tid + i * 256;
-            if (NL * 256 == NITEM || idx < NITEM) {
-                const int key_in = idx / D4, c4 = idx - key_in * D4;
-                *reinterpret_cast<f32x4*>(base + key_in * PITCH + c4 * 4) = st[i];
-            }
-        }
-    };
-    auto scores = [&](const float* Ks, f32x4& s0, f32x4& s1) __attribute__((always_inline)) {
-        f32x4 kf0[DT], kf1[DT];
-        const float* kp = Ks + r16 * PITCH + kq * 4;
-#pragma unroll
-        for (int j = 0; j < DT; ++j) { kf0[j] = *reinterpret_cast<const f32x4*>(kp + j * 16); kf1[j] = *reinterpret_cast<const f32x4*>(kp + 16 * PITCH + j * 16); }
-        s0 = f32x4{0.f, 0.f, 0.f, 0.f};
-        s1 = s0;
-#pragma unroll
-        for (int j = 0; j < DT; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf0[j][e], qf[j][e], s0, 0, 0, 0);
-                s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf1[j][e], qf[j][e], s1, 0, 0, 0);
-            }
-    };
-
-    f32x4 oacc[DT];
-#pragma unroll
-    for (int j = 0; j < DT; ++j) oacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m_run = -INFINITY, l_run = 0.f;
-
-    // prologue: K(0) -> scores of stage 0; K(1) and V(0) staged behind it
-    load_rows(0, stk, ks_base, kc_base);
-    store_rows(smem, stk);
-    __syncthreads();
-    load_rows(min(1, ntiles - 1), stk, ks_base, kc_base);
-    load_rows(0, stv, vs_base, vc_base);
-    f32x4 c0, c1;
-    scores(smem, c0, c1);
-    store_rows(smem + TILE, stk);
-    store_rows(smem + 2 * TILE, stv);
-    __syncthreads();
-
-    for (int kt = 0; kt < ntiles; ++kt) {
-        load_rows(min(kt + 2, ntiles - 1), stk, ks_base, kc_base);  // past the end: re-reads of the last tile (cache hits), never consumed
-        load_rows(min(kt + 1, ntiles - 1), stv, vs_base, vc_base);
-        __builtin_amdgcn_sched_barrier(0);
-        const float* Kn = smem + ((kt + 1) & 1) * TILE;
-        const float* Vc = smem + 2 * TILE + (kt & 1) * TILE;
-        const int key0 = kt * KTILE;
-
-        // stream 1 (matrix core): the scores of stage kt + 1 (after the last stage: of stale K rows, dropped)
-        f32x4 n0, n1;
-        scores(Kn, n0, n1);
-
-        // stream 2 (VALU): online softmax of stage kt
-        float p[8];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int key = key0 + kq * 4 + r;
-            p[r] = key < Lk ? c0[r] : -INFINITY;
-            p[4 + r] = key + 16 < Lk ? c1[r] : -INFINITY;
-        }
-        float mt = fmaxf(fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3])), fmaxf(fmaxf(p[4], p[5]), fmaxf(p[6], p[7])));
-        mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
-        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-        const float m_new = fmaxf(m_run, mt);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // first stage: exp2(-inf) = 0
-        float psum = 0.f;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            p[r] = __builtin_amdgcn_exp2f(p[r] - m_new);  // masked keys: 0, which also zeroes their (clamped) V rows
-            psum += p[r];
-        }
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
-        if constexpr (KW) {
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const int wi = key0 + (r >> 2) * 16 + kq * 4 + (r & 3) - (Lk - n_kw);
-                const float wv = key_weights[min(max(wi, 0), n_kw - 1)];
-                p[r] *= (wi >= 0 && wi < n_kw) ? wv : 1.0f;
-            }
-        }
-        float vf0[DT][4], vf1[DT][4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float* vp = Vc + (kq * 4 + e) * PITCH + r16;
-#pragma unroll
-            for (int j = 0; j < DT; ++j) { vf0[j][e] = vp[j * 16]; vf1[j][e] = vp[16 * PITCH + j * 16]; }
-        }
-#pragma unroll
-        for (int j = 0; j < DT; ++j) oacc[j] *= alpha;
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int j = 0; j < DT; ++j) oacc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf0[j][e], p[e], oacc[j], 0, 0, 0);
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int j = 0; j < DT; ++j) oacc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf1[j][e], p[4 + e], oacc[j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        store_rows(smem + (kt & 1) * TILE, stk);                    // K(kt + 2) over K(kt), whose scores were taken one stage ago
-        store_rows(smem + 2 * TILE + ((kt + 1) & 1) * TILE, stv);   // V(kt + 1) over V(kt - 1)
+        if constexpr (STG != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's part of the next stage has landed before the barrier that publishes it
+        else store_tile(slot ^ 1);
         __syncthreads();
-        c0 = n0;
-        c1 = n1;
     }
     float l = l_run;
     l += __shfl_xor(l, 16, 64);
@@ -974,7 +622,7 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(AttnArgs args) {
     }
 }
 
-static std::atomic<int> g_attn_variant{0};  // test hook (test_hooks.h): 1 = force the register-fed kernel for large query counts too; 10 / 11 / 12 = LDS-staged kernel variant 0 / 1 / 2 at head_dim 80 (A/B probes)
+static std::atomic<int> g_attn_variant{0};  // test hook (test_hooks.h): 1 = register-fed kernel for large query counts too; 10 / 11 = LDS kernel with staging 0 / 1 (A/B probes; default: staging 2 at odd head_dim / 16, else 1)
 extern "C" int paella_test_attention_variant(int v) { g_attn_variant = v; return PAELLA_OK; }
 
 int launch_attention(const AttnArgs& a, hipStream_t st) {
@@ -1005,32 +653,17 @@ int launch_attention(const AttnArgs& a, hipStream_t st) {
     // small query counts (batch-1 sampling grids) are latency chains -> split keys over waves; large ones re-read K/V
     // once per workgroup, so give a workgroup 64 queries instead
     const bool ksplit = a.Lq < 256;
-    const bool lds = !ksplit && g_attn_variant != 1;
-    dim3 grid(ksplit ? (a.Lq + 15) / 16 : (a.Lq + 63) / 64, a.nhead, a.B);
-#define ATT_CASE(n)                                                                                        \
-    case n:                                                                                                \
-        if (ksplit) hipLaunchKernelGGL((attention_kernel<n, true>), grid, dim3(256), 0, st, a);            \
-        else if (lds) hipLaunchKernelGGL((attention_lds_kernel<n>), grid, dim3(256), 0, st, a);            \
-        else hipLaunchKernelGGL((attention_kernel<n, false>), grid, dim3(256), 0, st, a);                  \
-        break;
     const int variant = g_attn_variant.load();
-    if (lds && a.D == 80 && variant >= 10 && variant <= 23 && variant != 14) {
-        if (variant == 10) hipLaunchKernelGGL((attention_lds_kernel<5, 0>), grid, dim3(256), 0, st, a);
-        else if (variant == 11) hipLaunchKernelGGL((attention_lds_kernel<5, 1>), grid, dim3(256), 0, st, a);
-        else if (variant == 12) hipLaunchKernelGGL((attention_lds_kernel<5, 2>), grid, dim3(256), 0, st, a);
-        else if (variant == 15) hipLaunchKernelGGL((attention_lds_kernel<5, 5>), grid, dim3(256), 0, st, a);
-        else if (variant == 16) hipLaunchKernelGGL((attention_lds_kernel<5, 6>), grid, dim3(256), 0, st, a);
-        else if (variant == 18) hipLaunchKernelGGL((attention_lds_kernel<5, 1, 0, 1>), grid, dim3(256), 0, st, a);
-        else if (variant == 19) hipLaunchKernelGGL((attention_lds_kernel<5, 5, 0, 1>), grid, dim3(256), 0, st, a);
-        else if (variant == 21) hipLaunchKernelGGL((attention_lds_kernel<5, 5, 1>), grid, dim3(256), 0, st, a);
-        else if (variant == 22) hipLaunchKernelGGL((attention_lds_kernel<5, 5, 2>), grid, dim3(256), 0, st, a);
-        else if (variant == 23) hipLaunchKernelGGL((attention_lds_kernel<5, 5, 3>), grid, dim3(256), 0, st, a);
-        else if (variant == 17 && a.key_weights) hipLaunchKernelGGL((attention_pipe_kernel<5, true>), grid, dim3(256), 0, st, a);
-        else if (variant == 17) hipLaunchKernelGGL((attention_pipe_kernel<5, false>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((attention_lds_kernel<5, 3>), grid, dim3(256), 0, st, a);
-        LAUNCH_CHECK_RET();
-        return PAELLA_OK;
-    }
+    const bool lds = !ksplit && variant != 1;
+    dim3 grid(ksplit ? (a.Lq + 15) / 16 : (a.Lq + 63) / 64, a.nhead, a.B);
+#define ATT_CASE(n)                                                                                                     \
+    case n:                                                                                                             \
+        if (ksplit) hipLaunchKernelGGL((attention_kernel<n, true>), grid, dim3(256), 0, st, a);                         \
+        else if (lds && variant == 10) hipLaunchKernelGGL((attention_lds_kernel<n, 0>), grid, dim3(256), 0, st, a);     \
+        else if (lds && variant == 11) hipLaunchKernelGGL((attention_lds_kernel<n, 1>), grid, dim3(256), 0, st, a);     \
+        else if (lds) hipLaunchKernelGGL((attention_lds_kernel<n, (n & 1) ? 2 : 1>), grid, dim3(256), 0, st, a);        \
+        else hipLaunchKernelGGL((attention_kernel<n, false>), grid, dim3(256), 0, st, a);                               \
+        break;
     switch (a.D / 16) {
         case 1:  // head_dim 16 (toy models): the LDS-staged instantiation spills; the register-fed kernel serves large query counts there
             if (ksplit) hipLaunchKernelGGL((attention_kernel<1, true>), grid, dim3(256), 0, st, a);

@@ -20,8 +20,9 @@ int paella_test_attention_bf16(const unsigned short* q16, const unsigned short* 
 int paella_test_gemm_bf16_rule(int mask);
 /* launches n_launches dependent, nearly empty kernels (blocks x 256 threads touching n_elems floats): boundary floor */
 int paella_test_launch_chain(float* buf, int n_elems, int blocks, int n_launches, void* stream);
-/* 1 = run large-query-count attention on the register-fed kernel instead of the LDS-staged one; 10 / 11 / 12 = LDS-staged kernel variant 0 / 1 / 2 at head_dim 80
- * (attention.hip: VAR; bit-identical outputs); 0 = default (A/B probe, tools/attn_probe.py) */
+/* 1 = run large-query-count attention on the register-fed kernel instead of the LDS-staged one; 10 = LDS-staged kernel with register staging (rounds 2-5),
+ * 11 = its padded direct-to-LDS layout at every head_dim; 0 = default = direct-to-LDS staging, unpadded (4 workgroups per CU) at odd head_dim / 16, padded otherwise
+ * (attention.hip: STG; bit-identical outputs; A/B probe tools/attn_probe.py) */
 int paella_test_attention_variant(int v);
 /* C = prologue(A) . W^T with an explicit tile config / workgroup count (as paella_op_gemm): mode 1: a' = a * scale[row / rows_per_sample][k] +
  * shift[k] (the GRN apply of the MLP's second GEMM); mode 2: a' = (a - mean) * rstd from ln_stats [M, K/16, 2] = per 16-column block (sum, M2 =

@@ -364,6 +364,39 @@ def test_attention(lib, B, nh, D, Lq, Ls, Lc, nkw):
     np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), atol=2e-5, rtol=1e-4)
 
 
+@pytest.mark.parametrize("D", [32, 48, 64, 80, 96, 112, 128])
+@pytest.mark.parametrize("Lq,Ls,Lc,nkw", [(257, 257, 21, 4), (256, 0, 300, 0), (320, 320, 64, 0), (300, 40, 500, 3)])
+def test_attention_lds_stagings_are_bit_identical(lib, D, Lq, Ls, Lc, nkw):
+    """>= 256 queries: the LDS-staged kernel with direct-to-LDS K/V tiles (the product path: unpadded 4-workgroups-per-CU layout at odd D/16, padded otherwise), the padded layout everywhere, the register-staged
+    build and the register-fed kernel do the same arithmetic in the same order -> identical bits; the shapes put the self / conditioning boundary and the end of
+    the keys inside a 32-key stage, and cover conditioning-only keys."""
+    B, nh = 2, 2
+    C = nh * D
+    g = torch.Generator(device="cuda").manual_seed(D + Lq + Lc)
+    q = torch.randn(B, Lq, C, device="cuda", generator=g)
+    ks, vs = torch.randn(B, max(Ls, 1), C, device="cuda", generator=g), torch.randn(B, max(Ls, 1), C, device="cuda", generator=g)
+    kc, vc = torch.randn(B, Lc, C, device="cuda", generator=g), torch.randn(B, Lc, C, device="cuda", generator=g)
+    kw = torch.rand(nkw, device="cuda", generator=g) * 2 if nkw else None
+    outs = {}
+    try:
+        for variant in (0, 1, 10, 11):
+            lib.paella_test_attention_variant(variant)
+            out = torch.full((B, Lq, C), float("nan"), device="cuda")
+            _check(lib, lib.paella_op_attention(_p(q), _p(ks) if Ls else None, _p(vs) if Ls else None, _p(kc), _p(vc), _p(out), B, nh, D, Lq, Ls, Lc, _p(kw), nkw, _st()))
+            outs[variant] = out
+    finally:
+        lib.paella_test_attention_variant(0)
+    for variant in (1, 10, 11):
+        assert torch.equal(outs[0], outs[variant]), "staging variant %d differs from the product kernel by %g" % (variant, float((outs[0] - outs[variant]).abs().max()))
+    k = torch.cat([ks[:, :Ls], kc], 1).view(B, Ls + Lc, nh, D).permute(0, 2, 1, 3).double()
+    v = torch.cat([vs[:, :Ls], vc], 1).view(B, Ls + Lc, nh, D).permute(0, 2, 1, 3).double()
+    att = ((q.view(B, Lq, nh, D).permute(0, 2, 1, 3).double() @ k.transpose(-1, -2)) / D ** 0.5).softmax(-1)
+    if nkw:
+        att[..., -nkw:] *= kw.double()
+    ref = (att @ v).permute(0, 2, 1, 3).reshape(B, Lq, C).float()
+    np.testing.assert_allclose(outs[0].cpu().numpy(), ref.cpu().numpy(), atol=2e-5, rtol=1e-4)
+
+
 def test_attention_online_softmax_rescale_branch(lib):
     """Spike one key far above the rest in a late tile so the running max jumps (guide rule 26)."""
     B, nh, D, Lq, Lc = 1, 1, 16, 16, 70
