@@ -662,7 +662,7 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (WM * WN == 8 ? 1 : TM * T
                     if constexpr (APRO == 2) {
                         if (!ln_dir[i]) a = (a - *reinterpret_cast<const f32x4*>(g.ln_wsum + nn) * fr_mu[i]) * fr_rs[i];  // the folded LayerNorm (see ln_row_stats)
                     }
-                    v = epilogue_apply(g.ep, g.N, m, nn, a);
+                    v = epilogue_apply<BF>(g.ep, g.N, m, nn, a);
                     epilogue_write(g.ep, g.C, g.ldc, m, nn, v);
                 }
                 if constexpr (GRN_FIN) {

@@ -22,12 +22,31 @@ __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
 
-// bias -> activation -> alpha -> residual -> timestep scale/shift
+// GELU of the opt-in bf16 fast mode's epilogues (bf16 operands: the accumulator already carries ~1e-3 relative operand-rounding error and the MLP hidden tensor it
+// feeds is stored as bf16, 2^-9 relative).  libm's erff is ~37 VALU instructions with a divergent branch -- at bf16 MFMA rates that is AS LONG as the K = 1280 main loop
+// of an MLP's first GEMM and 3x the K = 384 one.  Branch-free, 12 instructions, no transcendental:
+//     gelu(x) = max(x, 0) - |x| Q(|x|),   Q(a) = 1 - Phi(a) ~ (4 - a)+ . R(a),  R = degree-6 minimax fit on [0, 4] (weighted by the error it causes in gelu)
+// max |gelu_fast - gelu| = 1.27e-4 over all x (equi-oscillating; |x| >= 4 returns max(x, 0), true value differs by <= 4 Q(4) = 1.27e-4).  The exact fp32 path never uses it.
+__device__ __forceinline__ float gelu_fast(float x) {
+    const float a = fabsf(x);
+    const float d = fmaxf(4.0f - a, 0.0f);
+    float r = -4.582215843e-05f;
+    r = fmaf(r, a, 1.208787551e-03f);
+    r = fmaf(r, a, -1.008340903e-02f);
+    r = fmaf(r, a, 3.467543423e-02f);
+    r = fmaf(r, a, -3.520498052e-02f);
+    r = fmaf(r, a, -6.194137782e-02f);
+    r = fmaf(r, a, 1.242401227e-01f);
+    return fmaf(-(a * d), r, fmaxf(x, 0.0f));
+}
+
+// bias -> activation -> alpha -> residual -> timestep scale/shift (FASTG: the bf16-operand kernels' GELU)
+template <bool FASTG = false>
 __device__ __forceinline__ f32x4 epilogue_apply(const Epilogue& ep, int N, int m, int n, f32x4 v) {
     if (ep.bias) v += *reinterpret_cast<const f32x4*>(ep.bias + n);
     if (ep.act == ACT_GELU) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = gelu_erf(v[i]);
+        for (int i = 0; i < 4; ++i) v[i] = FASTG ? gelu_fast(v[i]) : gelu_erf(v[i]);
     }
     if (ep.alpha != 1.0f) v *= ep.alpha;
     if (ep.residual) v += *reinterpret_cast<const f32x4*>(ep.residual + (size_t)m * ep.ldr + n);
