@@ -18,8 +18,24 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// GELU(erf) of the exact path: 0.5 x (1 + erf(x / sqrt 2)) with erf(a) = sign . (1 - 2^-P(|a|)), P = a degree-8 fit of -log2 erfc on [0, 3.92] (erfc(3.92) < 2^-25: the
+// clamp IS erf = 1 in fp32), ONE range, no branch: 15 instructions + one v_exp_f32.  libm's erff is two ranges behind a divergent branch (~37 instructions, both sides
+// executed by a wave whose lanes straddle |x| = 1 -- every wave of an MLP epilogue).  GELU needs erf to ABSOLUTE accuracy only (it enters as 1 + erf), which is what the
+// one-range form gives: max |gelu - exact| = 5.5e-7 over [-8, 8] against 6.8e-7 for 0.5 x (1 + erff(.)) evaluated in fp32 (both are the final roundings at large |x|;
+// fit and comparison: tools/fit_gelu.py).
 __device__ __forceinline__ float gelu_erf(float x) {
-    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+    const float a = fminf(fabsf(x) * 0.70710678118654752440f, 3.92f);
+    float q = 3.501229730e-05f;
+    q = fmaf(q, a, -3.597551840e-04f);
+    q = fmaf(q, a, 1.208558562e-03f);
+    q = fmaf(q, a, 1.240070444e-03f);
+    q = fmaf(q, a, -2.866797522e-02f);
+    q = fmaf(q, a, 1.486749798e-01f);
+    q = fmaf(q, a, 9.183741808e-01f);
+    q = fmaf(q, a, 1.627911687e+00f);
+    const float e = copysignf(1.0f - __builtin_amdgcn_exp2f(-(q * a)), x);
+    const float h = 0.5f * x;
+    return fmaf(h, e, h);
 }
 
 // GELU of the opt-in bf16 fast mode's epilogues (bf16 operands: the accumulator already carries ~1e-3 relative operand-rounding error and the MLP hidden tensor it
