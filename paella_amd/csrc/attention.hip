@@ -207,7 +207,8 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
 //       duplicate of its last chunk) rounded up to whole wave instructions; a stage whose 32 keys are all self rows or all conditioning rows (every stage but at
 //       most two) addresses with per-lane offsets computed ONCE plus one scalar offset per stage; the mixed stages clamp and select per lane.  No staging
 //       registers, no ds_write: 138 -> 110 VGPRs at head_dim 80 and 0.70-0.72 -> 0.77-0.80 of the fp32 MFMA peak.
-//       K tile: the K.Q^T fragment of a lane is 16 contiguous bytes of one key row -> ds_read_b128; row pitch D/4 + 1 (odd) 16-byte slots.
+//       K tile: the K.Q^T fragment of a lane is 16 contiguous bytes of one key row -> ds_read_b128; row pitch D/4 + 1 (odd) 16-byte slots: 2-way conflicts remain
+//       (a b128 lane group is 8 rows of one chunk column + 8 OTHER rows of the next; tests/test_attention_layout.py mirrors both layouts against the banking rules).
 //       V tile: the V^T.P^T fragment of a lane is V[key = 4*kq + e][d = 16*j + r16] -> ds_read_b32; lanes r16 sweep 16 consecutive banks and
 //       4*(D + 4) mod 32 = 16 puts kq = 0 / 1 on disjoint halves: conflict-free.
 //   2 = STG 1 without any padding (odd D/16 only): a tile is exactly [32][D] floats = 10 wave instructions at head_dim 80 and a workgroup's two stages are
