@@ -58,3 +58,13 @@ def test_ring_tile_residency_table_matches_the_compiler(built_lib):
         assert per_cu * 256 >= table, "ring tile %d (prologue %d): the host launches up to %d workgroups as resident, the kernel admits %d per CU (%s)" % (cfg, apro, table, per_cu, k)
         seen += 1
     assert seen >= 20
+
+
+def test_attention_unpadded_layout_really_fits_four_workgroups_per_cu(built_lib):
+    """attention_lds_kernel<5, 2> (head_dim 80, the 1B model): the unpadded direct-to-LDS layout exists to run FOUR workgroups per CU -- that needs <= 128 VGPRs, exactly
+    40 960 B of LDS (no other static LDS in the kernel) and the SGPR admission rule to allow 4 waves per SIMD; the padded layout of the same head_dim stops at three."""
+    ks = {k["name"]: k for k in _kernels(built_lib) if k["name"].startswith("_Z20attention_lds_kernel")}
+    unp, pad = ks["_Z20attention_lds_kernelILi5ELi2EEv8AttnArgs"], ks["_Z20attention_lds_kernelILi5ELi1EEv8AttnArgs"]
+    per_cu = lambda k: min(k["occupancy"], 8, 800 // (-(-k["sgpr"] // 16) * 16 + 16), (160 * 1024) // k["lds"])
+    assert unp["lds"] == 40960 and unp["vgpr"] + (unp["agpr"] or 0) <= 128 and per_cu(unp) == 4, unp
+    assert per_cu(pad) == 3, pad
