@@ -173,8 +173,67 @@ def make_train_golden(ref, name="train_tiny_step"):
     save(name, names=np.array(names), checksum=np.array(synth.checksum(sd)), **out)
 
 
+def make_nonsquare_goldens(ref):
+    """H != W fixtures (VERDICT r05 item 3).  The reference is fully convolutional (src/modules.py:130-134,153-156,172-183;
+    src/vqgan.py:54-89): any token grid divisible by the down-sampling factor runs.  These pin the space-to-depth / depth-to-space /
+    pixel-shuffle / k2s2 / 4-phase convT index maps of the HIP path for H != W: UNET_TINY forward at (2,16,32) and (1,24,8),
+    the sample() closed loop at (1,16,32), VQModel(levels=2 / 3) encode / decode / decode_indices at 64x128 / 128x256 px."""
+    with torch.no_grad():
+        cfg = G.UNET_TINY
+        m, sd = make_ref_unet(ref["modules"], cfg, G.WEIGHT_SEED)
+        arrays = {}
+        for tag, (B, H, W), seed in (("wide", (2, 16, 32), 17), ("tall", (1, 24, 8), 18)):
+            g = torch.Generator().manual_seed(seed)
+            x = torch.randint(0, cfg["num_labels"], (B, H, W), generator=g)
+            r = torch.rand(B, generator=g)
+            c = cond_for(cfg, B, 5, 1, G.COND_SEED + seed)
+            logits = m(x, r, **c)
+            lo = O.unet_forward(sd, cfg, x, r, **c)
+            assert torch.allclose(lo, logits, atol=2e-5, rtol=1e-5), (lo - logits).abs().max()
+            arrays.update({tag + "_x": x, tag + "_r": r, tag + "_logits": logits})
+        save("unet_tiny_forward_nonsquare", checksum=np.array(synth.checksum(sd)), keys=keyshapes(sd), **arrays)
+
+        # sample(), src/utils.py signature, on a 16x32 grid
+        B1, H1, W1 = 1, 16, 32
+        cs = cond_for(cfg, B1, 4, 0, G.COND_SEED)
+        us = cond_for(cfg, B1, 4, 0, G.COND_SEED + 5)
+        torch.manual_seed(G.SAMPLER_SEED + 7)
+        toks = ref["utils"].sample(m, cs, (B1, H1, W1), unconditional_inputs=us, steps=8, renoise_steps=7, temperature=(1.0, 0.2),
+                                   cfg=8.0, device="cpu")
+        noise = O.replay_torch_noise(G.SAMPLER_SEED + 7, (B1, H1, W1), cfg["num_labels"], 8, 7)
+        t_list = [float(v) for v in torch.linspace(1.0, 0.0, 9)]
+        temps = [float(v) for v in torch.linspace(1.0, 0.2, 8)]
+        cf = (float(torch.tensor(8.0)), float(torch.tensor(1.0 - 8.0)))
+        fwd = lambda tk, rr, **inp: O.unet_forward(sd, cfg, tk, rr, **inp)
+        otoks, traj = O.sample(fwd, cfg["num_labels"], cs, us, (B1, H1, W1), steps=8, renoise_steps=7, temperatures=temps,
+                               cfgs=[cf] * 8, t_list=t_list, noise=noise)
+        assert torch.equal(otoks, toks), "oracle sample loop does not reproduce the reference on the 16x32 grid"
+        save("sample_tiny_nonsquare", tokens=toks, traj=torch.stack(traj))
+
+        for name, vc, (hp, wp) in (("vq_tiny_f4_nonsquare", G.VQ_TINY_F4, (64, 128)), ("vq_tiny_f8_nonsquare", G.VQ_TINY_F8, (128, 256))):
+            torch.manual_seed(0)
+            vq = ref["vqgan"].VQModel(**vc).eval()
+            vsd = synth.synth_state_dict(vq.state_dict(), seed=G.WEIGHT_SEED, n_blocks=vc["bottleneck_blocks"])
+            vq.load_state_dict(vsd)
+            gq = torch.Generator().manual_seed(6)
+            img = torch.rand(1, 3, hp, wp, generator=gq)
+            qe, lat, idx, loss = vq.encode(img)
+            dec = vq.decode(qe)
+            dec_i = vq.decode_indices(idx)
+            oq, olat, oidx, oloss = O.vq_encode(vsd, vc, img)
+            assert torch.equal(oidx, idx) and torch.allclose(olat, lat, atol=1e-5)
+            assert torch.allclose(O.vq_decode_indices(vsd, vc, idx), dec_i, atol=2e-5)
+            assert torch.allclose(O.vq_decode(vsd, vc, qe), dec, atol=2e-5)
+            # the image is a function of the seed (torch.rand on a seeded CPU generator): tests regenerate it and check img_sum
+            save(name, img_sum=np.array(float(img.double().sum())), qe=qe, lat=lat, idx=idx, loss=loss, dec=dec, dec_idx=dec_i,
+                 checksum=np.array(synth.checksum(vsd)), keys=keyshapes(vsd))
+
+
 def main():
     ref = import_reference()
+    if "--only-nonsquare" in sys.argv:
+        make_nonsquare_goldens(ref)
+        return
     if "--only-train" in sys.argv:
         for name in TRAIN_GOLDENS:
             make_train_golden(ref, name)
@@ -295,6 +354,7 @@ def main():
             assert torch.allclose(O.vq_decode(vsd, vc, qe), dec, atol=2e-5)
             save(name, img=img, qe=qe, lat=lat, idx=idx, loss=loss, dec=dec, dec_idx=dec_i, checksum=np.array(synth.checksum(vsd)),
                  keys=keyshapes(vsd))
+    make_nonsquare_goldens(ref)
     print("done")
 
 
