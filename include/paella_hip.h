@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PAELLA_ABI_VERSION 4
+#define PAELLA_ABI_VERSION 5
 
 #define PAELLA_OK 0
 #define PAELLA_ERR_ARG -1       /* invalid argument / unsupported shape */
@@ -112,7 +112,8 @@ int paella_unet_r_embedding(paella_unet* m, const float* r, int B, float max_pos
  * multiple of 64 through bf16-operand MFMA (v_mfma_f32_16x16x32_bf16, fp32 accumulation): bf16 shadow weights (made here / refreshed by finalize), bf16
  * activations between producer and consumer GEMMs (the 4c-wide MLP hidden tensor, LayerNorm and attention outputs, a bf16 copy of the residual stream where
  * a LayerNorm-folding GEMM reads it); the residual stream, statistics, attention, logits and the sampling tail stay fp32.  Mode 0 (default) is the exact
- * fp32 path, bit for bit.  Size workspaces (paella_unet_workspace_bytes) AFTER switching: mode 1 needs room for the bf16 activations. */
+ * fp32 path, bit for bit.  Size workspaces (paella_unet_workspace_bytes) AFTER switching: mode 1 needs room for the bf16 activations.  The shadows stay
+ * allocated until paella_unet_destroy (a HIP graph captured in mode 1 never dangles) and the switch to mode 0 does not synchronise. */
 int paella_unet_set_precision(paella_unet* m, int mode, void* stream);
 int paella_unet_get_precision(const paella_unet* m);
 
@@ -185,6 +186,13 @@ int paella_add_noise(const int64_t* x, const float* t, const int64_t* mask_in, c
                      const float* rand_u, uint64_t seed, uint64_t offset, int num_labels, int B,
                      int64_t per_sample, int64_t* x_out, int64_t* mask_out, void* stream);
 
+/* Token select on the [B,H,W] grid: out[i] = keep(i) ? a[i] : (b ? b[i] : fill) with keep(i) = (mask == NULL || mask[i] != 0) && (flag == NULL ||
+ * *flag == 1.0f).  `flag` is a DEVICE fp32 word.  Replaces the two integer elementwise expressions of the eval path that used to run through ATen: the
+ * inpainting wrapper's `out * mask + tokens * (1 - mask)` (the recipe src/modules.py:277-283 + src_distributed/utils.py:97-109, extension keep_known) and
+ * the batch-sharded sampler's "-1 when the conditioning broadcast was flagged invalid" (paella_amd/dist.py); no host synchronisation, graph-capturable. */
+int paella_select_tokens(const int64_t* a, const int64_t* b, const int64_t* mask, const float* flag, int64_t fill, int64_t n,
+                         int64_t* out, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * VQGAN (reference src/vqgan.py:45-107)
  * ---------------------------------------------------------------------------------------------- */
@@ -198,11 +206,11 @@ int paella_vqgan_create(const paella_vqgan_config* cfg, paella_vqgan** out);
 void paella_vqgan_destroy(paella_vqgan* v);
 int paella_vqgan_load_tensor(paella_vqgan* v, const char* key, const float* dev_src, const int64_t* shape, int ndim,
                              void* stream);
-int paella_vqgan_finalize(paella_vqgan* v, void* stream);
+int paella_vqgan_finalize(paella_vqgan* v, void* stream); /* synchronises the stream once (reads the BatchNorm statistics / ResBlock gammas to the host) */
 /* OPT-IN fast mode of ONE VQGAN (outside the fp32 parity contract, as paella_unet_set_precision): mode 1 runs the MLP of every ResBlock whose width is a
  * multiple of 64 on bf16-operand MFMA with fp32 accumulation (bf16 shadow weights, bf16 LayerNorm output and hidden tensor); everything else stays fp32.
  * Mode 0 (default) is the exact path.  Size workspaces (paella_vqgan_workspace_bytes) AFTER switching. */
-int paella_vqgan_set_precision(paella_vqgan* v, int mode, void* stream); /* synchronises the stream once (reads BN stats / gammas) */
+int paella_vqgan_set_precision(paella_vqgan* v, int mode, void* stream); /* mode 1 on a finalized model converts the shadows and waits for them; mode 0 frees nothing and never synchronises */
 /* h, w = latent grid; covers decode and encode of the matching image size */
 size_t paella_vqgan_workspace_bytes(const paella_vqgan* v, int B, int h, int w);
 /* decode_indices (src/vqgan.py:103-107): idx int64 [B,h,w] -> image fp32 NCHW [B,3,f*h,f*w], f = 2^levels */

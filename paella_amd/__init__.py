@@ -11,11 +11,11 @@ Everything executes through libpaella_hip.so (hand-written HIP for gfx950, C ABI
 The opt-in bf16 fast mode is a per-model switch: `Paella.set_gemm_precision("bf16")` (outside the fp32 parity contract).
 """
 from .conditioning import build_paella, embed_prompts, load_checkpoint, load_conditional_models
-from .editing import inpaint
+from .editing import GraphInpainter, inpaint
 from .modules import CondCache, DenoiseUNet, Paella, replace_attention_layers
-from .sampling import GraphSampler, sample, sample_distributed
+from .sampling import GraphSampler, sample, sample_distributed, select_tokens
 from .vqgan import VectorQuantize, VQModel
 
 
 __all__ = ["Paella", "DenoiseUNet", "CondCache", "VQModel", "VectorQuantize", "sample", "sample_distributed", "GraphSampler",
-           "replace_attention_layers", "inpaint", "load_conditional_models", "embed_prompts", "load_checkpoint", "build_paella"]
+           "replace_attention_layers", "inpaint", "GraphInpainter", "select_tokens", "load_conditional_models", "embed_prompts", "load_checkpoint", "build_paella"]

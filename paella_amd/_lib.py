@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libpaella_hip.so")
 
 MAX_LEVELS = 8
 MAX_BLOCK_TYPES = 8
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class UnetConfig(Structure):
@@ -67,6 +67,7 @@ SIGNATURES = {
     "paella_start_tokens": (c_int, [c_uint64, c_void_p, c_int64, c_void_p, c_int, c_int64, c_void_p, c_void_p]),
     "paella_add_noise": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint64, c_uint64, c_int, c_int,
                                  c_int64, c_void_p, c_void_p, c_void_p]),
+    "paella_select_tokens": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     "paella_vqgan_create": (c_int, [POINTER(VqganConfig), POINTER(c_void_p)]),
     "paella_vqgan_destroy": (None, [c_void_p]),
     "paella_vqgan_load_tensor": (c_int, [c_void_p, c_char_p, c_void_p, POINTER(c_int64), c_int, c_void_p]),

@@ -655,7 +655,10 @@ int launch_attention(const AttnArgs& a, hipStream_t st) {
     // once per workgroup, so give a workgroup 64 queries instead
     const bool ksplit = a.Lq < 256;
     const int variant = g_attn_variant.load();
-    const bool lds = !ksplit && variant != 1;
+    // the direct-to-LDS stagings address K / V with 32-bit byte offsets behind a buffer descriptor whose num_records is clamped to 2 GiB: a per-sample K / V
+    // span beyond that would be range-checked to zeros silently -- such a call takes the register-fed kernel, which uses 64-bit pointers
+    const bool span32 = (size_t)a.Lself * (size_t)a.ld_self * 4 < ((size_t)1 << 31) && (size_t)a.Lcond * (size_t)a.ld_cond * 4 < ((size_t)1 << 31);
+    const bool lds = !ksplit && variant != 1 && span32;
     dim3 grid(ksplit ? (a.Lq + 15) / 16 : (a.Lq + 63) / 64, a.nhead, a.B);
 #define ATT_CASE(n)                                                                                                     \
     case n:                                                                                                             \

@@ -285,6 +285,9 @@ int launch_add_noise(const int64_t* x, const float* t, const int64_t* mask_in, c
                      const float* rand_u, uint64_t seed, uint64_t offset, int num_labels, int B,
                      int64_t per_sample, int64_t* x_out, int64_t* mask_out, hipStream_t stream);
 
+// out[i] = ((mask == null || mask[i] != 0) && (flag == null || *flag == 1.0f)) ? a[i] : (b ? b[i] : fill)   (tail.hip)
+int launch_select_tokens(const int64_t* a, const int64_t* b, const int64_t* mask, const float* flag, int64_t fill, int64_t n, int64_t* out, hipStream_t stream);
+
 // VQGAN helpers
 int launch_codebook_gather(const int64_t* idx, const float* codebook, float* out, int64_t rows, int D, int K,
                            float scale, hipStream_t stream);

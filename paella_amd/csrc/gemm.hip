@@ -1398,16 +1398,15 @@ static SiteG g_sites[96] = {
     // bf16 fast mode (profiles/r05_site_tune_b1_bf16.txt: 24 sites, 1 moved, -0.45 %)
     {32, 1280, 1280, 0, 1, 200},    // attention out-projection, 16-position level (rule: 40)
 };
-static std::atomic<int> g_nsites{0};
-static int g_nsites_builtin = -1;
+// the built-in entries are counted in a static initialiser (before any launch can race on it); run-time overrides are appended behind them
+static int count_builtin_sites() {
+    int n = 0;
+    while (n < 96 && g_sites[n].M > 0) ++n;
+    return n;
+}
+static const int g_nsites_builtin = count_builtin_sites();
+static std::atomic<int> g_nsites{g_nsites_builtin};
 static int site_lookup(int M, int N, int K, int apro, int bf) {
-    if (g_nsites_builtin < 0) {  // count the built-in entries once (zero-initialised tail)
-        int n = 0;
-        while (n < 96 && g_sites[n].M > 0) ++n;
-        g_nsites_builtin = n;
-        int expect = 0;
-        g_nsites.compare_exchange_strong(expect, n);
-    }
     const int n = g_nsites.load(std::memory_order_acquire);
     for (int i = n - 1; i >= 0; --i)  // (later entries -- run-time overrides -- win)
         if (g_sites[i].M == M && g_sites[i].N == N && g_sites[i].K == K && g_sites[i].apro == apro && g_sites[i].bf == bf) return g_sites[i].G;
@@ -1415,7 +1414,6 @@ static int site_lookup(int M, int N, int K, int apro, int bf) {
 }
 // test hook: G > 0 sets / overrides a site, G == 0 removes the run-time entries of that site, M == 0 removes every run-time entry
 extern "C" int paella_test_gemm_site(int M, int N, int K, int apro, int bf, int G) {
-    (void)site_lookup(1, 1, 1, 0, 0);
     int n = g_nsites.load();
     if (M == 0) { g_nsites = g_nsites_builtin; return PAELLA_OK; }
     for (int i = n - 1; i >= g_nsites_builtin; --i)

@@ -445,12 +445,9 @@ extern "C" int paella_unet_set_precision(paella_unet* m, int mode, void* stream)
     if (mode != 0 && mode != 1) { paella_set_error("precision mode must be 0 (fp32) or 1 (bf16 operands)"); return PAELLA_ERR_ARG; }
     m->precision = mode;
     if (mode == 1 && m->finalized) return make_shadows(m, (hipStream_t)stream);
-    if (mode == 0) {
-        HIP_CHECK_RET(hipDeviceSynchronize());  // launches that read the shadows may still be in flight
-        for (auto& kv : m->t16) if (kv.second.p) (void)hipFree(kv.second.p);
-        for (auto& kv : m->wsum16) if (kv.second.p) (void)hipFree(kv.second.p);
-        m->t16.clear(); m->wsum16.clear();
-    }
+    // mode 0: the bf16 shadows stay allocated until paella_unet_destroy: a HIP graph captured in the fast mode keeps raw pointers to them, so a
+    // replay after the switch reads stale-but-live memory instead of freed memory (the Python GraphSampler refuses / recaptures such a graph anyway), and
+    // nothing here synchronises, so the call is legal while another stream is capturing.  A later switch back to mode 1 refreshes them (make_shadows).
     return PAELLA_OK;
 }
 extern "C" int paella_unet_get_precision(const paella_unet* m) { return m ? m->precision : 0; }
@@ -1117,6 +1114,12 @@ extern "C" int paella_add_noise(const int64_t* x, const float* t, const int64_t*
                                 int64_t* mask_out, void* stream) {
     if (!x || !x_out || (!mask_in && !t)) { paella_set_error("null argument"); return PAELLA_ERR_ARG; }
     return launch_add_noise(x, t, mask_in, random_x, rand_u, seed, offset, num_labels, B, per_sample, x_out, mask_out, (hipStream_t)stream);
+}
+
+extern "C" int paella_select_tokens(const int64_t* a, const int64_t* b, const int64_t* mask, const float* flag, int64_t fill, int64_t n, int64_t* out,
+                                    void* stream) {
+    if (n < 0) { paella_set_error("select_tokens: negative count"); return PAELLA_ERR_ARG; }
+    return launch_select_tokens(a, b, mask, flag, fill, n, out, (hipStream_t)stream);
 }
 
 extern "C" int paella_op_gemm(const float* A, const float* W, const float* bias, const float* residual, float* C, int M, int N, int K,

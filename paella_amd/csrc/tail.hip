@@ -232,6 +232,31 @@ int launch_add_noise(const int64_t* x, const float* t, const int64_t* mask_in, c
 }
 
 // ---------------------------------------------------------------------------
+// Token select: out[i] = keep(i) ? a[i] : (b ? b[i] : fill), keep(i) = (mask == null || mask[i] != 0) && (flag == null || *flag == 1.0f).
+// Two users, both integer elementwise work on the [B, H, W] grid that used to go through ATen: the inpainting wrapper re-imposes the known tokens
+// (`out * mask + tokens * (1 - mask)`, paella_amd/editing.py -- an extension of the recipe src/modules.py:277-283 + src_distributed/utils.py:97-109) and the
+// batch-sharded sampler replaces a receiver's tokens by -1 when the conditioning broadcast carried a zero validity flag (paella_amd/dist.py).  `flag` is a
+// DEVICE word, so neither needs a host round trip and both can be captured in a HIP graph.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void select_tokens_kernel(const int64_t* __restrict__ a, const int64_t* __restrict__ b, const int64_t* __restrict__ mask,
+                                                            const float* __restrict__ flag, int64_t fill, int64_t n, int64_t* __restrict__ out) {
+    const bool ok = flag ? (*flag == 1.0f) : true;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const bool keep = ok && (mask ? mask[i] != 0 : true);
+        out[i] = keep ? a[i] : (b ? b[i] : fill);
+    }
+}
+int launch_select_tokens(const int64_t* a, const int64_t* b, const int64_t* mask, const float* flag, int64_t fill, int64_t n, int64_t* out, hipStream_t st) {
+    if (n <= 0) return PAELLA_OK;
+    if (!a || !out) { paella_set_error("select_tokens: null argument"); return PAELLA_ERR_ARG; }
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(select_tokens_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, b, mask, flag, fill, n, out);
+    LAUNCH_CHECK_RET();
+    return PAELLA_OK;
+}
+
+// ---------------------------------------------------------------------------
 // test hook (test_hooks.h): the scores the counter-based tail maximises, written out -- score[row][i] = mix(l_c, l_u)[i] / T - log q_i
 // with exactly the kernels' arithmetic and Philox counters.  Lets a test classify a differing token by the decision margin
 // (top-1 minus top-2 score) instead of bounding a mismatch count.

@@ -243,11 +243,7 @@ extern "C" int paella_vqgan_set_precision(paella_vqgan* v, int mode, void* strea
     if (mode != 0 && mode != 1) { paella_set_error("precision mode must be 0 (fp32) or 1 (bf16 operands)"); return PAELLA_ERR_ARG; }
     v->precision = mode;
     if (mode == 1 && v->finalized) return vq_make_shadows(v, (hipStream_t)stream);
-    if (mode == 0) {
-        HIP_CHECK_RET(hipDeviceSynchronize());
-        for (auto& kv : v->t16) if (kv.second.p) (void)hipFree(kv.second.p);
-        v->t16.clear();
-    }
+    // mode 0: shadows stay allocated until paella_vqgan_destroy (see paella_unet_set_precision); no synchronisation here
     return PAELLA_OK;
 }
 

@@ -219,8 +219,14 @@ def sample_sharded(model, model_inputs, unconditional_inputs, latent_shape, src=
     With the counter-based noise (default here) every random number -- start tokens, categorical draws, renoise mask -- is
     keyed by (seed, GLOBAL row, step), so the concatenation of the shards equals the unsharded `sample(..., noise="philox",
     seed=seed)` bit for bit, whatever the world size.  noise="torch" consumes each rank's own torch generator
-    (no cross-rank equivalence; the reference has none either)."""
-    from .sampling import sample
+    (no cross-rank equivalence; the reference has none either).
+    FAILURE CONTRACT (a source-side conditioning that does not match the agreed `layout`; detectable on the source's host only): the broadcast stays
+    well-formed (agreed size, NaN payload, flag word 0) and every rank stays in its collective sequence.  gather=True: every rank raises ValueError after
+    the all_gather.  gather=False: the SOURCE raises ValueError; every RECEIVER returns a token grid filled with -1 (set on the device from the flag word,
+    no host synchronisation) -- callers on that path must treat negative tokens as "request failed" before decoding them.  Receivers still run their
+    sampling pass on the NaN conditioning (skipping it would need a host read of the flag on every healthy call); its tokens stay inside [0, num_labels)
+    -- the tail's argmax keeps the first label on NaN scores -- so the next step's embedding gather never indexes out of range."""
+    from . import sampling as S  # (looked up at call time: tests/test_dist.py substitutes CPU stand-ins for the two HIP entry points)
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     device = next(model.parameters()).device
     philox = noise == "philox"
@@ -240,9 +246,9 @@ def sample_sharded(model, model_inputs, unconditional_inputs, latent_shape, src=
         if src_bad:
             local = torch.full((hi - lo, H, W), -1, dtype=torch.int64, device=device)
         else:
-            local = sample(model, shard_inputs(cond, lo, hi), (hi - lo, H, W), unconditional_inputs=shard_inputs(uncond, lo, hi),
-                           device=device, noise=noise, seed=0 if philox else seed, seed_dev=seed_dev, shard=shard, **kwargs)
-            local = torch.where(ok_dev.to(local.device) == 1.0, local, torch.full_like(local, -1))
+            local = S.sample(model, shard_inputs(cond, lo, hi), (hi - lo, H, W), unconditional_inputs=shard_inputs(uncond, lo, hi),
+                             device=device, noise=noise, seed=0 if philox else seed, seed_dev=seed_dev, shard=shard, **kwargs)
+            local = S.select_tokens(local, flag=ok_dev, fill=-1)  # one HIP kernel on the device flag word: tokens, or -1 everywhere when the flag is 0
     if not gather:
         if src_bad:
             raise ValueError("conditioning does not match the agreed layout (a poisoned buffer of the agreed size was broadcast: the other ranks return -1 tokens)")

@@ -113,6 +113,27 @@ def timestep_table(t_list, steps, B, device):
     return torch.tensor([float(v) for v in t_list[:steps]], dtype=torch.float32).to(device)[:, None].repeat(1, B).contiguous()
 
 
+def select_tokens(a, b=None, mask=None, flag=None, fill=-1, out=None):
+    """out[i] = keep(i) ? a[i] : (b[i] if b is given else fill), keep(i) = (mask is None or mask[i] != 0) and (flag is None or flag[0] == 1.0) -- int64 token
+    grids, `flag` a 1-element fp32 DEVICE tensor (paella_select_tokens: one HIP kernel, no host synchronisation, graph-capturable).  Used by the inpainting
+    wrapper (re-impose the known tokens) and by the batch-sharded sampler (-1 tokens when the conditioning broadcast was flagged invalid)."""
+    dev = a.device
+    if dev.type != "cuda" or a.dtype != torch.int64:
+        raise ValueError("select_tokens needs int64 HIP tensors")
+    a = a.contiguous()
+    for name, t in (("b", b), ("mask", mask)):
+        if t is not None and (t.dtype != torch.int64 or t.shape != a.shape or t.device != dev):
+            raise ValueError("select_tokens: %s must be an int64 tensor of a's shape on a's device" % name)
+    if flag is not None and (flag.dtype != torch.float32 or flag.numel() != 1 or flag.device != dev):
+        raise ValueError("select_tokens: flag must be a 1-element fp32 tensor on a's device")
+    if out is None:
+        out = torch.empty_like(a)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().paella_select_tokens(_lib.ptr(a), _lib.ptr(None if b is None else b.contiguous()), _lib.ptr(None if mask is None else mask.contiguous()),
+                                                    _lib.ptr(flag), int(fill), a.numel(), _lib.ptr(out), _lib.stream_ptr(dev)))
+    return out
+
+
 def _sample_core(model, model_inputs, unconditional_inputs, latent_shape, init_x, steps, renoise_steps, t_list, temperatures,
                  cfgs, device, noise="torch", seed=None, attn_weights=None, seed_dev=None, init_noise_buf=None, r_all=None, shard=None,
                  ws=None, fused_tail=True, row_offset_dev=None):
@@ -288,11 +309,17 @@ class GraphSampler:
     inside the graph as functions of (seed, global row, step): `sampler(seed=s, shard=(lo, total))` returns exactly rows
     [lo, lo + B) of `sample(..., noise="philox", seed=s)` over the global batch (tests/test_gpu_sample.py).
     seed=None draws a fresh seed from torch's global CPU generator (one draw per call; see fresh_seed).
-    """
+
+    Staleness (the call site that reloads weights between sampling calls is src/train.py:40,64-69,76): a capture bakes raw pointers,
+    host-side constants read from the weights (the VQGAN's ResBlock gammas) and the precision mode's kernel choice.  Every replay first compares the models'
+    parameter signature (data_ptr + version of every tensor) and precision with what the capture saw; on a difference it RECAPTURES (on_stale="recapture",
+    default: the replay then equals a fresh eager call bit for bit) or raises a RuntimeError naming the cause (on_stale="raise")."""
 
     def __init__(self, model, model_inputs, unconditional_inputs, latent_shape, steps=12, renoise_steps=11, temperature=(1.0, 0.2),
-                 cfg=8.0, t_start=1.0, t_end=0.0, device="cuda", vqgan=None, attn_weights=None):
-        self.model, self.vqgan, self.device = model, vqgan, torch.device(device)
+                 cfg=8.0, t_start=1.0, t_end=0.0, device="cuda", vqgan=None, attn_weights=None, on_stale="recapture"):
+        if on_stale not in ("recapture", "raise"):
+            raise ValueError("on_stale must be 'recapture' or 'raise'")
+        self.model, self.vqgan, self.device, self.on_stale = model, vqgan, torch.device(device), on_stale
         self.shape = tuple(int(v) for v in latent_shape)
         self.kw = dict(steps=steps, renoise_steps=renoise_steps, temperature=temperature, cfg=cfg, t_start=t_start, t_end=t_end)
         self.attn_weights = attn_weights
@@ -303,26 +330,42 @@ class GraphSampler:
         self.row_offset_dev = torch.zeros(1, dtype=torch.int64, device=self.device)  # lo * H * W of the shard being sampled
         self.init_noise = torch.zeros(self.shape, dtype=torch.int64, device=self.device)
         self.r_all = timestep_table(linspace_schedule(t_start, t_end, steps + 1), steps, self.shape[0], self.device)
+        self.captures = 0
+        self._capture()
+
+    # ---- what a capture depends on besides the shapes
+    def _state(self):
+        st = [("denoiser weights", self.model._signature()), ("denoiser gemm precision", self.model._precision)]
+        if self.vqgan is not None:
+            st += [("VQGAN weights", self.vqgan._signature()), ("VQGAN gemm precision", self.vqgan._precision)]
+        return st
+
+    def _capture(self):
         # The graph bakes raw pointers: it owns its workspaces (the modules' own scratch is dropped and reallocated whenever a
-        # later eager call needs a bigger one) and it is the only user of their split-K tickets.
+        # later eager call needs a bigger one) and it is the only user of their split-K tickets.  Sized here: the fast mode needs more room.
         B, H, W = self.shape
-        S = max(_cond_seq_len(model, self.cond), _cond_seq_len(model, self.uncond), 1)
-        self.ws = _lib.new_workspace(model.workspace_bytes(2 * B, H, W, S), self.device)
-        self.vq_ws = None if vqgan is None else _lib.new_workspace(vqgan.workspace_bytes(B, H, W), self.device)
+        S = max(_cond_seq_len(self.model, self.cond), _cond_seq_len(self.model, self.uncond), 1)
+        self.graph = self.out = None
+        self.ws = _lib.new_workspace(self.model.workspace_bytes(2 * B, H, W, S), self.device)
+        self.vq_ws = None if self.vqgan is None else _lib.new_workspace(self.vqgan.workspace_bytes(B, H, W), self.device)
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):
-            for _ in range(2):  # warm-up: weights loaded, workspaces sized, allocator pools populated
+            for _ in range(2):  # warm-up: weights (re)loaded, workspaces sized, allocator pools populated
                 self._run()
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
-        self.graph = torch.cuda.CUDAGraph()
+        state = self._state()  # AFTER the warm-up: the engines are loaded with exactly these tensors
+        graph = torch.cuda.CUDAGraph()
         # thread_local: a process-group watchdog thread polling events must not invalidate the capture
-        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-            self.out = self._run()
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            out = self._run()
         torch.cuda.synchronize(self.device)
+        self.graph, self.out, self._captured_state = graph, out, state
+        self.captures += 1
 
-    def _run(self):
+    def _schedule(self):
+        """(t_list, temperatures, per-step guidance pairs) of the src/utils.py:35 signature"""
         k = self.kw
         t_list = linspace_schedule(k["t_start"], k["t_end"], k["steps"] + 1)
         temps = linspace_schedule(k["temperature"][0], k["temperature"][1], k["steps"])
@@ -331,9 +374,22 @@ class GraphSampler:
             cfgs = [pair] * k["steps"]
         else:
             cfgs = [None] * k["steps"]
-        toks = _sample_core(self.model, self.cond, self.uncond, self.shape, None, k["steps"], k["renoise_steps"], t_list, temps, cfgs,
+        return t_list, temps, cfgs
+
+    def _init_x(self):
+        """tokens the loop starts from (None = the Philox start tokens); GraphInpainter encodes + renoises an image here"""
+        return None
+
+    def _finish(self, toks):
+        return toks
+
+    def _run(self):
+        k = self.kw
+        t_list, temps, cfgs = self._schedule()
+        toks = _sample_core(self.model, self.cond, self.uncond, self.shape, self._init_x(), k["steps"], k["renoise_steps"], t_list, temps, cfgs,
                             self.device, noise="philox", seed=0, attn_weights=self.attn_weights, seed_dev=self.seed_dev,
                             init_noise_buf=self.init_noise, r_all=self.r_all, ws=self.ws, row_offset_dev=self.row_offset_dev)
+        toks = self._finish(toks)
         return toks if self.vqgan is None else (toks, self.vqgan.decode_indices(toks, ws=self.vq_ws))
 
     @staticmethod
@@ -358,15 +414,17 @@ class GraphSampler:
                     raise ValueError("conditioning shape differs from the captured one (%s)" % key)
                 d.copy_(s)
 
-    def __call__(self, model_inputs=None, unconditional_inputs=None, seed=None, shard=None):
-        """Replay. Returns tokens (and the decoded image if a VQGAN was given); outputs live in graph-owned buffers that
-        the next replay overwrites.  seed=None draws a fresh seed from torch's CPU generator; the start tokens and all per-step
-        noise are functions of the seed and of the GLOBAL row: shard=(lo, total) makes this replay rows [lo, lo + B) of a
-        global batch of `total` (bit-identical to those rows of the unsharded call with the same seed)."""
-        if model_inputs is not None:
-            self._copy_inputs(self.cond, model_inputs)
-        if unconditional_inputs is not None:
-            self._copy_inputs(self.uncond, unconditional_inputs)
+    def _check_fresh(self):
+        now = self._state()
+        if now == self._captured_state:
+            return
+        causes = [a[0] for a, b in zip(now, self._captured_state) if a != b]
+        if self.on_stale == "raise":
+            raise RuntimeError("GraphSampler: the captured graph is stale -- changed since the capture: %s (load_state_dict / optimizer step / .to() / set_gemm_precision). "
+                               "Build a new GraphSampler or construct it with on_stale='recapture'." % ", ".join(causes))
+        self._capture()
+
+    def _set_words(self, seed, shard):
         if seed is None:
             seed = fresh_seed()
         lo = 0
@@ -376,5 +434,17 @@ class GraphSampler:
                 raise ValueError("shard=(lo, total): rows [lo, lo + %d) must lie inside the global batch" % self.shape[0])
         self.row_offset_dev.fill_(lo * self.shape[1] * self.shape[2])
         self.seed_dev.fill_(int(seed))
+
+    def __call__(self, model_inputs=None, unconditional_inputs=None, seed=None, shard=None):
+        """Replay. Returns tokens (and the decoded image if a VQGAN was given); outputs live in graph-owned buffers that
+        the next replay overwrites.  seed=None draws a fresh seed from torch's CPU generator; the start tokens and all per-step
+        noise are functions of the seed and of the GLOBAL row: shard=(lo, total) makes this replay rows [lo, lo + B) of a
+        global batch of `total` (bit-identical to those rows of the unsharded call with the same seed)."""
+        self._check_fresh()
+        if model_inputs is not None:
+            self._copy_inputs(self.cond, model_inputs)
+        if unconditional_inputs is not None:
+            self._copy_inputs(self.uncond, unconditional_inputs)
+        self._set_words(seed, shard)
         self.graph.replay()
         return self.out

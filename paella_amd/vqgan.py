@@ -132,13 +132,30 @@ class VQModel(nn.Module):
     def _device(self):
         return self.vquantizer.codebook.weight.device
 
+    def _signature(self):
+        """(data_ptr, version) of every parameter and buffer (the tensor list is cached; `_apply` and `refresh()` drop it) -- see Paella._signature."""
+        ts = self.__dict__.get("_sig_tensors")
+        if ts is None:
+            ts = list(self.parameters()) + list(self.buffers())
+            self.__dict__["_sig_tensors"] = ts
+        return tuple((t.data_ptr(), t._version) for t in ts)
+
+    def _apply(self, fn, *args, **kwargs):
+        self.__dict__["_sig_tensors"] = None
+        return super()._apply(fn, *args, **kwargs)
+
+    def refresh(self):
+        """Force a reload of every tensor on the next call (needed only after edits torch does not version, e.g. `p.data = ...` with a new storage of a NEW
+        Parameter object)."""
+        self._loaded_sig = None
+        self.__dict__["_sig_tensors"] = None
+
     def _engine(self):
         dev = self._device()
         if dev.type != "cuda":
             raise RuntimeError("paella_amd.VQModel executes only on a HIP device (module is on '%s'); there is no CPU fallback." % dev)
         lib = _lib.load()
-        tensors = [t for t in self.state_dict().values()]
-        sig = tuple((t.data_ptr(), t._version) for t in tensors)
+        sig = self._signature()
         if self._handle is not None and sig == self._loaded_sig:
             return self._handle
         with torch.cuda.device(dev):
@@ -205,8 +222,9 @@ class VQModel(nn.Module):
         return out
 
     # ------------------------------------------------------------------ reference surface
-    def encode(self, x):
-        """reference src/vqgan.py:91-95 -> (qe / sf, x / sf, indices, vq_loss + 0.25 * commit_loss)"""
+    def encode(self, x, ws=None):
+        """reference src/vqgan.py:91-95 -> (qe / sf, x / sf, indices, vq_loss + 0.25 * commit_loss).  ws: optional caller-owned workspace (a captured graph
+        must not depend on the module's growable scratch)."""
         h = self._engine()
         lib = _lib.load()
         dev = self._device()
@@ -223,7 +241,7 @@ class VQModel(nn.Module):
         idx = torch.empty(B, hh, ww, dtype=torch.int64, device=dev)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            ws = self._workspace(lib.paella_vqgan_workspace_bytes(h, B, hh, ww))
+            ws = self._workspace(lib.paella_vqgan_workspace_bytes(h, B, hh, ww), ws)
             _lib.check(lib.paella_vqgan_encode(h, _lib.ptr(x), B, Hp, Wp, _lib.ptr(qe), _lib.ptr(lat), _lib.ptr(idx), _lib.ptr(loss),
                                                _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)))
         return qe, lat, idx, loss[0]

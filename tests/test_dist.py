@@ -95,6 +95,8 @@ def _shard_worker(rank, world, port, q):
             return (toks + rows * 7 + int(torch.nan_to_num(model_inputs["clip"]).sum().round())) % model.num_labels  # (a poisoned, NaN-filled conditioning must not raise here: the HIP sampler does not either)
 
         S.sample = fake_sample
+        # stands in for paella_select_tokens (one HIP kernel on the device flag word): tokens where the broadcast's validity flag is 1, `fill` otherwise
+        S.select_tokens = lambda a, b=None, mask=None, flag=None, fill=-1, out=None: torch.where(flag == 1.0, a, torch.full_like(a, fill))
         g = torch.Generator().manual_seed(1)
         B, H, W = 5, 4, 4
         cond = {"byt5": torch.randn(B, 0, 8, generator=g), "clip": torch.randn(B, 6, generator=g), "clip_image": None}
