@@ -15,9 +15,14 @@ With N GPUs every rank generates its own batch (weak scaling); rank 0 owns the c
 broadcasts it once per step over RCCL (the only collective of the path).
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).  Besides the contract fields the line carries
-`throughput`: the same path at throughput batch sizes, each with its own in-run roofline -- on one GPU batch 32 at configs[1] and
-BASELINE configs[2] (batch 64, 64x64 tokens, 12 steps); on N GPUs batch 32 PER GPU through the same broadcast + shard path
-(whole-node images/s, max-over-ranks timing).
+`throughput`: the same path at throughput batch sizes, each with its own in-run roofline -- batch 32 / 64 / 128 at configs[1]'s model and grid (the
+BASELINE metric "256x256 @ 8 steps" at the batch where a GPU is busiest: `best_256px_8step`), BASELINE configs[2] (one GPU only), and the per-GPU shares
+of the two configurations BASELINE names for 8 GPUs: configs[3] (1B, batch 256 / 8 = 32 per GPU, 64x64 tokens, ByT5 + CLIP text + CLIP image) and
+configs[4] (1B, batch 128 / 8 = 16 per GPU, 128x128 tokens, the inpainting path).  On N GPUs every one of them goes through the SAME broadcast + shard path
+as the headline (rank 0 owns the conditioning of all N x batch images; whole-node images/s, max-over-ranks timing, per-workload broadcast_ms).
+
+Test-only flags (tests/test_gpu_dist.py): --rehearsal (every workload on the tiny model at small sizes, plus a sharded == unsharded check of the last
+step's tokens and images), --dist-backend gloo --share-device (N ranks on ONE device: the N > 1 code paths on a 1-GPU box), --inject-setup-failure R.
 """
 import argparse
 import ctypes
@@ -61,8 +66,13 @@ ALGO_GFLOP_PER_IMAGE = {("570m", 32, 8): 2 * 8 * 66.27 + 38.8, ("570m", 64, 12):
                         ("1b", 128, 12): 2 * 12 * (2164.0 - 110.4 - 224.3) + 2 * 110.4 + 621.0 + 16 * 12.2}
 # the throughput-regime workloads reported next to the headline: (model, batch per GPU, token grid, sampling steps, S_byt5, CLIP image embedding, inpainting path,
 # timed steps, warm-up steps, captured graph).  The 1B workloads run eagerly (one warm-up + one timed batch: a capture would cost three more passes of 4-7 s each).
-EXTRA_WORKLOADS = [("570m", 32, 32, 8, 0, 0, False, 3, 1, True), ("570m", 64, 64, 12, 0, 0, False, 2, 1, True),
-                   ("1b", 32, 64, 12, 256, 1, False, 1, 1, False), ("1b", 16, 128, 12, 256, 1, True, 1, 1, False)]
+EXTRA_WORKLOADS = [("570m", 32, 32, 8, 0, 0, False, 3, 1, True), ("570m", 64, 32, 8, 0, 0, False, 3, 1, True), ("570m", 128, 32, 8, 0, 0, False, 2, 1, True),
+                   ("570m", 64, 64, 12, 0, 0, False, 2, 1, True),
+                   ("1b", 32, 64, 12, 256, 1, False, 2, 1, True), ("1b", 16, 128, 12, 256, 1, True, 2, 1, True)]
+# N > 1: everything except configs[2] (a one-GPU configuration) and batch 64; the two 1B entries are the per-GPU shares of BASELINE's 8-GPU configurations
+EXTRA_DISTRIBUTED = [0, 2, 4, 5]
+# --rehearsal: the same table on the tiny model (every code path, seconds instead of minutes)
+REHEARSAL_WORKLOADS = [("tiny", 4, 16, 4, 0, 0, False, 2, 1, True), ("tiny", 3, 16, 4, 8, 1, False, 2, 1, True), ("tiny", 2, 16, 4, 8, 1, True, 2, 1, True)]
 # the kernel sources the roofline's PMC traffic figure belongs to (profiles/*_pmc_traffic.json is stamped with their hash)
 TRAFFIC_SOURCES = ["paella_amd/csrc/gemm.hip", "paella_amd/csrc/gemm_device.h", "paella_amd/csrc/philox.h", "paella_amd/csrc/tail.hip", "paella_amd/csrc/model.hip",
                    "paella_amd/csrc/common.h"]
@@ -90,6 +100,11 @@ def parse():
     ap.add_argument("--clip-image", type=int, default=0, help="number of CLIP image embeddings in the conditioning (configs[3] / configs[4]: 1)")
     ap.add_argument("--inpaint", action="store_true", help="the configs[4] path: VQGAN encode -> masked renoise -> sample(init_x, t_start 0.5) -> decode (eager)")
     ap.add_argument("--force-dist", action="store_true", help="take the torch.distributed (RCCL) path even at world size 1 (launch under torchrun)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="TEST ONLY: gloo moves device tensors through the host, which lets N ranks share one GPU")
+    ap.add_argument("--share-device", action="store_true", help="TEST ONLY: every rank uses cuda:0 (needs --dist-backend gloo; RCCL refuses two ranks on one device)")
+    ap.add_argument("--rehearsal", action="store_true", help="TEST ONLY: every workload on the tiny model at small sizes + a sharded == unsharded check of the results; "
+                                                             "the line is marked `rehearsal` and is not a measurement")
+    ap.add_argument("--inject-setup-failure", type=int, default=-1, metavar="RANK", help="TEST ONLY: the set-up of every throughput workload fails on this rank")
     return ap.parse_args()
 
 
@@ -256,103 +271,139 @@ def gemm_roofline(lib, run_once, device, model, batch, grid, sample_steps, gemm,
             "latency_model": latency_model}
 
 
-def main():
-    a = parse()
-    if a.gpus > 1 and "RANK" not in os.environ:
-        sys.exit(self_launch(a))
+class Ctx:
+    """what every workload of one bench.py process shares: arguments, rank / world, device, the library handle, the model zoo"""
 
-    import torch
-    import torch.distributed as dist
-    distributed = a.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1 or (a.force_dist and "RANK" in os.environ)
-    rank, world, local = 0, 1, 0
-    if distributed:
-        rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        if world != a.gpus and rank == 0:
-            print("bench.py: --gpus %d but the launcher started %d ranks; reporting the observed world size" % (a.gpus, world), file=sys.stderr)
-    device = torch.device("cuda", local)
-    torch.cuda.set_device(device)
+    def __init__(self, a, rank, world, device, distributed, lib):
+        self.a, self.rank, self.world, self.device, self.distributed, self.lib = a, rank, world, device, distributed, lib
+        self.zoo = {}
+        self.use_graph = not a.no_graph and a.noise == "philox"
 
-    import paella_amd
-    from paella_amd import _lib, synth
-    from paella_amd.dist import broadcast_conditioning, conditioning_layout, shard_bounds, shard_inputs
-    lib = _lib.load()  # fails loudly if the HIP library is missing
-    hooks = {}
-    for h in a.hook:
-        name, val = h.split("=")
-        _lib.check(getattr(lib, "paella_test_" + name)(int(val)))
-        hooks[name] = int(val)
-
-    mcfg, vcfg = MODELS[a.model], VQ[a.model]
-    zoo = {}
-
-    def get_model(name):
+    def get_model(self, name):
         """(denoiser, VQGAN, their synthetic state dicts) for a model name; built once, seeded synthetic weights (no checkpoints exist offline)"""
-        if name not in zoo:
+        import paella_amd
+        from paella_amd import synth
+        if name not in self.zoo:
             m = paella_amd.Paella(**MODELS[name])
             msd = synth.randomize_(m, seed=0)
-            m = m.to(device)
+            m = m.to(self.device)
             v = paella_amd.VQModel(**VQ[name])
             vsd = synth.randomize_(v, seed=0)
-            v = v.to(device)
-            zoo[name] = (m, v, msd, vsd)
-        return zoo[name]
+            v = v.to(self.device)
+            self.zoo[name] = (m, v, msd, vsd)
+        return self.zoo[name]
 
-    model, vq, unet_sd, vq_sd = get_model(a.model)
-    model.set_gemm_precision(a.gemm)  # per-model switch; "fp32" (default) = the exact path
-    vq.set_gemm_precision(a.gemm)
-    mk_cond = lambda n, seed, name=a.model, S_byt5=a.s_byt5, n_ci=a.clip_image: synth.synth_conditioning(n, S_byt5, MODELS[name]["byt5_embd"], MODELS[name]["clip_embd"], seed=seed,
-                                                                                        n_clip_image=n_ci, device=device)
+    def mk_cond(self, n, seed, name, S_byt5, n_ci):
+        from paella_amd import synth
+        return synth.synth_conditioning(n, S_byt5, MODELS[name]["byt5_embd"], MODELS[name]["clip_embd"], seed=seed, n_clip_image=n_ci, device=self.device)
 
-    total = a.batch * world
-    # rank 0 owns the conditioning of the whole job (as if it had run the CLIP text encoder); CLIP-text-only: S_byt5 = 0
-    cond_all = uncond_all = None
-    if rank == 0:
-        cond_all, uncond_all = mk_cond(total, 2), mk_cond(total, 3)
-    lo, hi = shard_bounds(total, rank, world)
-    # fixed request shapes: every rank derives the broadcast layout locally, so the per-step exchange is ONE async RCCL broadcast
-    tmpl = mk_cond(total, 2)
-    layout = conditioning_layout([tmpl, tmpl]) if distributed else None
-    use_graph = not a.no_graph and a.noise == "philox"
 
-    def make_runner(batch, grid, sample_steps, seed_base, name=None, S_byt5=a.s_byt5, n_ci=a.clip_image, inpaint=a.inpaint, graph=True):
-        """(step function replaying the captured graph or launching eagerly, eager step function for the profiling pass)"""
-        name = name or a.model
-        mdl, vqm = get_model(name)[:2]
-        counter = [0]
-        kw = dict(steps=sample_steps, renoise_steps=sample_steps - 1, temperature=(1.0, 0.2), cfg=8.0, device=device)
-        sampler = None
-        if use_graph and graph and not inpaint:  # capture sample() + decode once for these shapes; every step replays it with fresh conditioning / seed
-            sampler = paella_amd.GraphSampler(mdl, mk_cond(batch, 2, name, S_byt5, n_ci), mk_cond(batch, 3, name, S_byt5, n_ci), (batch, grid, grid), vqgan=vqm, **kw)
+def synth_images(lo, hi, px, device):
+    """rows [lo, hi) of the job's synthetic image batch: a function of the GLOBAL row (every rank draws only its own rows, rank 0 can redraw all of them)"""
+    import torch
+    return torch.stack([torch.rand(3, px, px, generator=torch.Generator().manual_seed(12000 + r)) for r in range(lo, hi)]).to(device)
 
-        # shard-exact noise: every rank keys its Philox draws with the SAME per-step seed and its GLOBAL row offset, so the N-GPU job
-        # produces exactly the images of the unsharded batch (tests/test_gpu_sample.py::test_graph_sampler_shard_equals_unsharded)
-        shard = (rank * batch, world * batch) if a.noise == "philox" else None
-        img = mask = None
+
+class Runner:
+    """One workload's step function on this rank: sample() (or the inpainting recipe) + VQGAN decode for `batch` images -- a captured HIP graph replayed per
+    step, or eager launches (the profiling pass always launches eagerly).  Shard-exact noise: every rank keys its Philox draws with the SAME per-step seed and
+    its GLOBAL row offset, so the N-GPU job produces exactly the images of the unsharded batch (tests/test_gpu_sample.py, tests/test_gpu_graph.py)."""
+
+    def __init__(self, ctx, name, batch, grid, sample_steps, S_byt5, n_ci, inpaint, graph, seed_base):
+        import torch
+
+        import paella_amd
+        self.ctx, self.name, self.batch, self.grid, self.sample_steps, self.inpaint, self.seed_base = ctx, name, batch, grid, sample_steps, inpaint, seed_base
+        self.mdl, self.vqm = ctx.get_model(name)[:2]
+        a, dev = ctx.a, ctx.device
+        self.kw = dict(steps=sample_steps, renoise_steps=sample_steps - 1, temperature=(1.0, 0.2), cfg=8.0, device=dev)
+        self.shard = (ctx.rank * batch, ctx.world * batch) if a.noise == "philox" else None
+        self.counter = 0
+        self.img = self.mask = None
         if inpaint:  # BASELINE configs[4]: VQGAN encode -> masked-token renoise -> sample(init_x, t_start < 1) -> decode (paella_amd/editing.py)
-            g = torch.Generator().manual_seed(12)
-            img = torch.rand(batch, 3, grid * 8, grid * 8, generator=g).to(device)
-            mask = torch.zeros(batch, grid, grid, dtype=torch.int64, device=device)
-            mask[:, grid // 4:3 * grid // 4, grid // 4:3 * grid // 4] = 1
-
-        def eager(c, u):
-            counter[0] += 1
+            self.img = synth_images(ctx.rank * batch, (ctx.rank + 1) * batch, grid * 8, dev)
+            self.mask = self.hole(batch, grid, dev)
+        self.sampler = None
+        if ctx.use_graph and graph:  # capture once for these shapes; every step replays it with fresh conditioning / seed / shard offset
+            c0, u0 = ctx.mk_cond(batch, 2, name, S_byt5, n_ci), ctx.mk_cond(batch, 3, name, S_byt5, n_ci)
             if inpaint:
-                return paella_amd.inpaint(mdl, vqm, img, mask, c, u, steps=sample_steps, t_start=0.5, noise="philox", seed=seed_base + 1000 * counter[0])[1]
-            toks = paella_amd.sample(mdl, c, (batch, grid, grid), unconditional_inputs=u, noise=a.noise, seed=seed_base + 1000 * counter[0], shard=shard, **kw)
-            return vqm.decode_indices(toks)
+                self.sampler = paella_amd.GraphInpainter(self.mdl, self.vqm, self.img, self.mask, c0, u0, steps=sample_steps, t_start=0.5, device=dev)
+            else:
+                self.sampler = paella_amd.GraphSampler(self.mdl, c0, u0, (batch, grid, grid), vqgan=self.vqm, **self.kw)
+        self.submission = "hip-graph replay" if self.sampler is not None else "eager launches"
 
-        def step(c, u):
-            if sampler is None:
-                return eager(c, u)
-            counter[0] += 1
-            return sampler(c, u, seed=seed_base + 1000 * counter[0], shard=shard)[1]
-        return step, eager
+    @staticmethod
+    def hole(batch, grid, dev):
+        import torch
+        mask = torch.zeros(batch, grid, grid, dtype=torch.int64, device=dev)
+        mask[:, grid // 4:3 * grid // 4, grid // 4:3 * grid // 4] = 1
+        return mask
 
-    step_fn, eager_fn = make_runner(a.batch, a.grid, a.sample_steps, 0)
-    ev = {"b": [], "r": []}  # per step: (start, after the conditioning broadcast + shard, after the replay) events -> broadcast_ms / graph_replay_ms of the line
+    def eager(self, c, u, seed):
+        import paella_amd
+        if self.inpaint:
+            return paella_amd.inpaint(self.mdl, self.vqm, self.img, self.mask, c, u, steps=self.sample_steps, t_start=0.5, noise="philox", seed=seed, shard=self.shard)
+        toks = paella_amd.sample(self.mdl, c, (self.batch, self.grid, self.grid), unconditional_inputs=u, noise=self.ctx.a.noise, seed=seed, shard=self.shard, **self.kw)
+        return toks, self.vqm.decode_indices(toks)
+
+    def step(self, c, u):
+        self.counter += 1
+        seed = self.seed_base + 1000 * self.counter
+        if self.sampler is None:
+            return self.eager(c, u, seed)
+        if self.inpaint:
+            return self.sampler(self.img, self.mask, c, u, seed=seed, shard=self.shard)
+        return self.sampler(c, u, seed=seed, shard=self.shard)
+
+    def unsharded(self, cond_all, uncond_all, seed):
+        """--rehearsal, rank 0: the same request as ONE batch of world x batch images (eager), to compare the gathered shards with"""
+        import paella_amd
+        total = self.batch * self.ctx.world
+        if self.inpaint:
+            img = synth_images(0, total, self.grid * 8, self.ctx.device)
+            return paella_amd.inpaint(self.mdl, self.vqm, img, self.hole(total, self.grid, self.ctx.device), cond_all, uncond_all, steps=self.sample_steps, t_start=0.5,
+                                      noise="philox", seed=seed)
+        toks = paella_amd.sample(self.mdl, cond_all, (total, self.grid, self.grid), unconditional_inputs=uncond_all, noise="philox", seed=seed, **self.kw)
+        return toks, self.vqm.decode_indices(toks)
+
+
+def run_workload(ctx, spec, steps, warmup, seed_base, fatal, with_latency_model=False):
+    """One workload through the path the N-GPU job takes: set-up (local) -> readiness agreement -> timed steps, each = [conditioning broadcast from rank 0 +
+    shard slicing] + sampler -> (rehearsal: sharded == unsharded check) -> rank 0's roofline pass -> barrier.
+    Returns a dict of measurements, or {"error": ...} when the set-up failed on ANY rank (never for fatal=True, the headline: exceptions propagate)."""
+    import torch
+    import torch.distributed as dist
+
+    from paella_amd.dist import broadcast_conditioning, cond_spec_layout, shard_bounds, shard_inputs
+    name, batch, grid, sample_steps, S_byt5, n_ci, inpaint, graph = spec
+    a, rank, world, device, distributed = ctx.a, ctx.rank, ctx.world, ctx.device, ctx.distributed
+    total = batch * world
+    err = run = cond_all = uncond_all = layout = None
+    lo, hi = shard_bounds(total, rank, world)
+    try:  # local set-up only (no collectives): models, rank 0's conditioning for the WHOLE job, graph capture
+        if not fatal and a.inject_setup_failure == rank:
+            raise RuntimeError("injected set-up failure on rank %d (--inject-setup-failure)" % rank)
+        mdl = ctx.get_model(name)[0]
+        if rank == 0:  # rank 0 owns the conditioning of all `total` images (as if it had run the text / image encoders) ...
+            cond_all, uncond_all = ctx.mk_cond(total, 2, name, S_byt5, n_ci), ctx.mk_cond(total, 3, name, S_byt5, n_ci)
+        # ... and every rank derives the broadcast layout from the request shapes alone, so the per-step exchange is ONE asynchronous broadcast
+        layout = cond_spec_layout(mdl, total, S_byt5=S_byt5, clip=True, n_clip_image=n_ci) if distributed else None
+        run = Runner(ctx, name, batch, grid, sample_steps, S_byt5, n_ci, inpaint, graph, seed_base)
+    except Exception as e:
+        if fatal:
+            raise
+        err = repr(e)
+    if distributed and not fatal:  # every rank must be ready before the first collective of this workload: agree, or skip it together
+        flag = torch.tensor([0 if err else 1], device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0 and err is None:
+            err = "set-up failed on another rank"
+    if err is not None:
+        del run
+        torch.cuda.empty_cache()
+        return {"error": err}
+
+    ev = {"b": [], "r": []}  # per step: (start, after the conditioning broadcast + shard, after the sampler) events -> broadcast_ms / graph_replay_ms
 
     def step():
         e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
@@ -363,98 +414,137 @@ def main():
         else:
             c, u = cond_all, uncond_all
         e1.record()
-        out = step_fn(c, u)
+        out = run.step(c, u)
         e2.record()
         ev["b"].append((e0, e1)); ev["r"].append((e1, e2))
         return out
 
-    dt, rank_dts = timed(step, a.steps, a.warmup, distributed, device)
-    images = total * a.steps
-    value = images / dt
-    ms_per_step = dt / a.steps * 1e3
-    ev_ms = lambda pairs: round(sum(x.elapsed_time(y) for x, y in pairs[-a.steps:]) / max(a.steps, 1), 4)
-    broadcast_ms, replay_ms = ev_ms(ev["b"]), ev_ms(ev["r"])
+    dt, per_rank = timed(step, steps, warmup, distributed, device)
+    ev_ms = lambda pairs: round(sum(x.elapsed_time(y) for x, y in pairs[-steps:]) / max(steps, 1), 4)
+    res = {"dt": dt, "total": total, "per_rank_ms": per_rank, "broadcast_ms": ev_ms(ev["b"]) if distributed else 0.0, "sampler_ms": ev_ms(ev["r"]),
+           "submission": run.submission, "broadcast_bytes": (layout[1] + 1) * 4 if distributed else 0}
 
-    roof = None
-    if rank == 0:
+    if a.rehearsal and a.noise == "philox":  # TEST ONLY: one more step, gathered, against the unsharded request on rank 0
+        toks, img = step()
+        seed = run.seed_base + 1000 * run.counter
+        toks, img = toks.clone(), img.clone()
+        if distributed:
+            tl, il = [torch.empty_like(toks) for _ in range(world)], [torch.empty_like(img) for _ in range(world)]
+            dist.all_gather(tl, toks)
+            dist.all_gather(il, img)
+            toks, img = torch.cat(tl), torch.cat(il)
+        if rank == 0:
+            ft, fi = run.unsharded(cond_all, uncond_all, seed)
+            res["rehearsal"] = {"tokens_equal_unsharded": bool(torch.equal(toks, ft)), "images_equal_unsharded": bool(torch.equal(img, fi)),
+                                "tokens": int(toks.numel()), "row_offsets": [r * batch * grid * grid for r in range(world)]}
+
+    if rank == 0:  # the roofline pass (eager launches, every GEMM bracketed by events) runs on rank 0 alone; the others wait at the barrier below
         c0, u0 = (cond_all, uncond_all) if not distributed else (shard_inputs(cond_all, lo, hi), shard_inputs(uncond_all, lo, hi))
-        roof = gemm_roofline(lib, lambda: eager_fn(c0, u0), device, a.model, a.batch, a.grid, a.sample_steps, a.gemm, True, with_latency_model=(a.batch == 1))
+        res["roofline"] = gemm_roofline(ctx.lib, lambda: run.eager(c0, u0, seed_base + 7), device, name, batch, grid, sample_steps, a.gemm, True,
+                                        with_latency_model=with_latency_model)
     if distributed:
         dist.barrier()
+    del run
+    torch.cuda.empty_cache()
+    return res
 
-    # ---- the same path at throughput batch sizes, each with its own in-run roofline.  One GPU: batch 32 at configs[1], BASELINE configs[2], and the per-GPU
-    # shares of configs[3] / configs[4] (released-size 1B model with ByT5 + CLIP text + CLIP image conditioning; configs[4] = the inpainting path).
-    # N GPUs: batch 32 PER GPU through the same broadcast + shard path (whole-node images/s, max-over-ranks timing). ----
+
+def main():
+    a = parse()
+    if a.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(a))
+
+    import torch
+    import torch.distributed as dist
+    distributed = a.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1 or (a.force_dist and "RANK" in os.environ)
+    rank, world, local = 0, 1, 0
+    if a.share_device and a.dist_backend != "gloo":
+        sys.exit("bench.py: --share-device needs --dist-backend gloo (RCCL refuses two ranks on one device)")
+    if distributed:
+        rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
+        if a.share_device:
+            local = 0
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        if a.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
+        if world != a.gpus and rank == 0:
+            print("bench.py: --gpus %d but the launcher started %d ranks; reporting the observed world size" % (a.gpus, world), file=sys.stderr)
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+
+    from paella_amd import _lib
+    lib = _lib.load()  # fails loudly if the HIP library is missing
+    hooks = {}
+    for h in a.hook:
+        name, val = h.split("=")
+        _lib.check(getattr(lib, "paella_test_" + name)(int(val)))
+        hooks[name] = int(val)
+    if a.rehearsal:  # TEST ONLY: the tiny model everywhere
+        a.model, a.grid, a.sample_steps = "tiny", 16, 4
+
+    ctx = Ctx(a, rank, world, device, distributed, lib)
+    model, vq, unet_sd, vq_sd = ctx.get_model(a.model)
+    model.set_gemm_precision(a.gemm)  # per-model switch; "fp32" (default) = the exact path
+    vq.set_gemm_precision(a.gemm)
+    mcfg, vcfg = MODELS[a.model], VQ[a.model]
+
+    # ---- the headline: BASELINE configs[1] unless flags say otherwise
+    head = run_workload(ctx, (a.model, a.batch, a.grid, a.sample_steps, a.s_byt5, a.clip_image, a.inpaint, True), a.steps, a.warmup, 0, fatal=True,
+                        with_latency_model=(a.batch == 1))
+    total = head["total"]
+    value = total * a.steps / head["dt"]
+    ms_per_step = head["dt"] / a.steps * 1e3
+    headline_cfg = (a.model == "570m" or a.rehearsal) and (a.batch, a.s_byt5, a.clip_image, a.inpaint) == (1, 0, 0, False) and (a.rehearsal or (a.grid, a.sample_steps) == (32, 8))
+
+    # ---- the same path at throughput batch sizes and on BASELINE's other configurations, each with its own in-run roofline (module docstring).  N GPUs: the
+    # SAME broadcast + shard path per workload (whole-node images/s, max-over-ranks timing); a set-up failure on any rank turns the entry into an `error`. ----
     throughput = None
-    if not a.no_extra and a.model == "570m" and (a.batch, a.grid, a.sample_steps) == (1, 32, 8):
+    if not a.no_extra and headline_cfg:
         throughput = []
-        for (en, eb, eg, es, sb, nci, inp, k, w, gr) in (EXTRA_WORKLOADS if not distributed else EXTRA_WORKLOADS[:1]):
+        table = REHEARSAL_WORKLOADS if a.rehearsal else ([EXTRA_WORKLOADS[i] for i in EXTRA_DISTRIBUTED] if distributed else EXTRA_WORKLOADS)
+        for (en, eb, eg, es, sb, nci, inp, k, w, gr) in table:
             if a.gemm != "fp32" and en != "570m":
                 continue
-            err = None
-            sfn = efn = None
-            try:  # local set-up only (no collectives): capture the graph for these shapes
-                tot_e = eb * world
-                ce_all = ue_all = None
-                if en != a.model:
-                    get_model(en)
-                if rank == 0:
-                    ce_all, ue_all = mk_cond(tot_e, 2, en, sb, nci), mk_cond(tot_e, 3, en, sb, nci)
-                lo_e, hi_e = shard_bounds(tot_e, rank, world)
-                tm_e = mk_cond(tot_e, 2, en, sb, nci)
-                lay_e = conditioning_layout([tm_e, tm_e]) if distributed else None
-                sfn, efn = make_runner(eb, eg, es, 50000 * eb, en, sb, nci, inp, gr)
-            except Exception as e:  # informational runs: never lose the headline line over them
-                err = repr(e)
-            if distributed:  # every rank must be ready before the first collective of the extra run
-                flag = torch.tensor([0 if err else 1], device=device)
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                if int(flag.item()) == 0 and err is None:
-                    err = "set-up failed on another rank"
-            if err is not None:
-                throughput.append({"model": en, "batch": eb, "grid": eg, "sample_steps": es, "error": err})
-                continue
-
-            def estep():
-                if distributed:
-                    c, u = broadcast_conditioning([ce_all, ue_all] if rank == 0 else None, src=0, device=device, layout=lay_e)
-                    c, u = shard_inputs(c, lo_e, hi_e), shard_inputs(u, lo_e, hi_e)
-                else:
-                    c, u = ce_all, ue_all
-                return sfn(c, u)
-
+            ident = {"model": en, "batch": eb, "grid": eg, "sample_steps": es}
             try:
-                dte, rk = timed(estep, k, w, distributed, device)
-                if rank == 0:
-                    c0e, u0e = (ce_all, ue_all) if not distributed else (shard_inputs(ce_all, lo_e, hi_e), shard_inputs(ue_all, lo_e, hi_e))
-                    r = gemm_roofline(lib, lambda: efn(c0e, u0e), device, en, eb, eg, es, a.gemm, True)
-                    npar = sum(p.numel() for p in get_model(en)[0].parameters())
-                    throughput.append({"workload": "%s: %s (%.1fM params), batch %d per GPU, %dx%d tokens, %d steps, CFG 8.0, conditioning S = %d (ByT5 %d + CLIP text 4%s), %s+ VQGAN f8 decode"
-                                                   % (WORKLOAD_TAG.get((en, eb, eg, es), "configs[1] model at a throughput batch"), "Paella v3 1B (default ctor)" if en == "1b" else "573M-class stand-in",
-                                                      npar / 1e6, eb, eg, eg, es, sb + 4 + 4 * nci, sb, " + CLIP image 4" if nci else "",
-                                                      "VQGAN encode + masked renoise + sample(init_x, t_start 0.5) " if inp else ""),
-                                       "model": en, "batch": eb, "n_gpus": world, "images_per_step": tot_e, "grid": eg, "sample_steps": es, "steps": k, "warmup": w,
-                                       "submission": "hip-graph replay" if (use_graph and gr and not inp) else "eager launches",
-                                       "images_per_sec": round(tot_e * k / dte, 3), "ms_per_image": round(dte / (tot_e * k) * 1e3, 3), "per_rank_ms": rk,
-                                       "roofline": {kk: r[kk] for kk in ("bound", "achieved", "peak", "unit", "frac", "executed_tflops", "executed_frac",
-                                                                          "launches_per_step", "avg_launch_us", "gemm_ms_per_step", "traffic", "traffic_source",
-                                                                          "algorithmic_bytes_per_launch", "algorithmic_gflop_per_image")}})
-            except Exception as e:  # (world size 1 only reaches here without a collective pending)
-                if distributed:
+                r = run_workload(ctx, (en, eb, eg, es, sb, nci, inp, gr), k, w, 50000 * eb + eg, fatal=False)
+            except Exception as e:
+                if distributed:  # past the readiness agreement a failure may leave the other ranks inside a collective: do not pretend otherwise
                     raise
-                throughput.append({"model": en, "batch": eb, "grid": eg, "sample_steps": es, "error": repr(e)})
-            if distributed:
-                dist.barrier()
-            del sfn, efn
-            torch.cuda.empty_cache()
+                r = {"error": repr(e)}
+            if "error" in r:
+                throughput.append(dict(ident, error=r["error"]))
+                continue
+            if rank != 0:
+                continue
+            tot_e, rf = r["total"], r["roofline"]
+            npar = sum(p.numel() for p in ctx.get_model(en)[0].parameters())
+            entry = dict(ident, workload="%s: %s (%.1fM params), batch %d per GPU, %dx%d tokens, %d steps, CFG 8.0, conditioning S = %d (ByT5 %d + CLIP text 4%s), %s+ VQGAN f8 decode"
+                         % (WORKLOAD_TAG.get((en, eb, eg, es), "configs[1] model at a throughput batch"), "Paella v3 1B (default ctor)" if en == "1b" else ("tiny test model" if en == "tiny" else "573M-class stand-in"),
+                            npar / 1e6, eb, eg, eg, es, sb + 4 + 4 * nci, sb, " + CLIP image 4" if nci else "",
+                            "VQGAN encode + masked renoise + sample(init_x, t_start 0.5) + re-imposed known tokens " if inp else ""),
+                         n_gpus=world, images_per_step=tot_e, steps=k, warmup=w, submission=r["submission"], scaling="weak",
+                         images_per_sec=round(tot_e * k / r["dt"], 3), ms_per_image=round(r["dt"] / (tot_e * k) * 1e3, 3), per_rank_ms=r["per_rank_ms"],
+                         broadcast_ms=r["broadcast_ms"], broadcast_mbytes=round(r["broadcast_bytes"] / 1e6, 2), sampler_ms=r["sampler_ms"],
+                         roofline={kk: rf[kk] for kk in ("bound", "achieved", "peak", "unit", "frac", "executed_tflops", "executed_frac", "launches_per_step", "avg_launch_us",
+                                                         "gemm_ms_per_step", "traffic", "traffic_source", "algorithmic_bytes_per_launch", "algorithmic_gflop_per_image")})
+            if "rehearsal" in r:
+                entry["rehearsal"] = r["rehearsal"]
+            throughput.append(entry)
         if rank != 0:
             throughput = None
 
     # ---- the OPT-IN bf16 fast mode (per-model switch, outside the parity contract), driver-timed as a SEPARATE entry: the headline stays fp32 ----
     fast_mode = None
-    if not a.no_extra and a.gemm == "fp32" and not distributed and a.model == "570m" and (a.batch, a.grid, a.sample_steps) == (1, 32, 8):
+    if not a.no_extra and a.gemm == "fp32" and not distributed and not a.rehearsal and headline_cfg:
         try:
-            fast_mode = run_fast_mode(lib, device, model, vq, mk_cond, make_runner)
+            def make_runner(eb, eg, es, seed_base):
+                r = Runner(ctx, a.model, eb, eg, es, 0, 0, False, True, seed_base)
+                return r.step, (lambda c, u: r.eager(c, u, seed_base + 7))
+            fast_mode = run_fast_mode(lib, device, model, vq, lambda n, seed: ctx.mk_cond(n, seed, a.model, 0, 0), make_runner)
         except Exception as e:
             fast_mode = {"error": repr(e)}
         finally:
@@ -462,33 +552,51 @@ def main():
             vq.set_gemm_precision("fp32")
 
     cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:  # the CPU baseline is an N = 1 figure
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and not a.rehearsal:  # the CPU baseline is an N = 1 figure
         try:
-            cpu = cpu_baseline(mcfg, vcfg, a.grid, a.sample_steps, unet_sd, vq_sd, cond_all, uncond_all)
+            c1, u1 = ctx.mk_cond(1, 2, a.model, a.s_byt5, a.clip_image), ctx.mk_cond(1, 3, a.model, a.s_byt5, a.clip_image)
+            cpu = cpu_baseline(mcfg, vcfg, a.grid, a.sample_steps, unet_sd, vq_sd, c1, u1)
         except Exception as e:  # the baseline is informational; never lose the GPU line over it
             cpu = {"value": None, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port", "sample": "failed: %r" % (e,)}
 
     if rank == 0:
         n_params = sum(p.numel() for p in model.parameters())
+        # the BASELINE metric "images/sec, 256x256 @ 8 steps" at the batch where a GPU is busiest: the best of the headline and the 32x32-token
+        # / 8-step throughput entries of THIS run
+        best = None
+        if a.model == "570m" and (a.grid, a.sample_steps) == (32, 8):
+            cands = [{"batch_per_gpu": a.batch, "images_per_sec": round(value, 3), "ms_per_image": round(ms_per_step / total, 3), "executed_frac": head["roofline"]["executed_frac"]}]
+            for t in throughput or []:
+                if "error" not in t and (t["model"], t["grid"], t["sample_steps"]) == ("570m", 32, 8):
+                    cands.append({"batch_per_gpu": t["batch"], "images_per_sec": t["images_per_sec"], "ms_per_image": t["ms_per_image"], "executed_frac": t["roofline"]["executed_frac"]})
+            best = dict(max(cands, key=lambda c: c["images_per_sec"]), n_gpus=world, note="whole-job images/s of the 573M-class model at 32x32 tokens / 8 steps / CFG 8 + f8 decode, "
+                        "fp32, at the best per-GPU batch measured in this run (the headline `value` stays batch 1 per GPU = BASELINE configs[1])")
         line = {
             "metric": "images/sec (whole node) + single-image ms, 256x256 @ 8 steps", "value": round(value, 4), "unit": "images/sec",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
             "single_image_ms": round(ms_per_step / a.batch, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if a.gemm == "fp32" else "bf16 MFMA operands / f32 accumulate and f32 everywhere else (opt-in fast mode, outside the parity contract)", "data": "synthetic (seeded random-init weights, random CLIP-text embeddings)",
-            "config": {"workload": WORKLOAD_TAG.get((a.model, a.batch, a.grid, a.sample_steps), "custom") + ": Paella 573M-class (stand-in blocks=[4,8,4], %.1fM params), %dx%d tokens = %d px, "
-                                   "%d steps, CFG 8.0, CLIP-H-text only (S=4), batch %d per GPU, + VQGAN f8 decode"
-                                   % (n_params / 1e6, a.grid, a.grid, a.grid * 8, a.sample_steps, a.batch),
+            "config": {"workload": WORKLOAD_TAG.get((a.model, a.batch, a.grid, a.sample_steps), "custom") + ": Paella %s (%.1fM params), %dx%d tokens = %d px, "
+                                   "%d steps, CFG 8.0, %s, batch %d per GPU, + VQGAN f8 decode"
+                                   % ("573M-class (stand-in blocks=[4,8,4])" if a.model == "570m" else a.model, n_params / 1e6, a.grid, a.grid, a.grid * 8, a.sample_steps,
+                                      "CLIP-H-text only (S=4)" if (a.s_byt5, a.clip_image) == (0, 0) else "S = %d (ByT5 %d + CLIP text 4%s)" % (a.s_byt5 + 4 + 4 * a.clip_image, a.s_byt5, " + CLIP image 4" if a.clip_image else ""),
+                                      a.batch),
                        "denoiser": a.model,
                        "images_per_gpu_per_step": a.batch, "images_per_step": total, "token_grid": a.grid, "sample_steps": a.sample_steps,
-                       "noise": a.noise, "submission": "hip-graph replay" if use_graph else "eager launches",
+                       "noise": a.noise, "submission": head["submission"],
                        "parallelism": "batch-shard x%d, one conditioning broadcast per step, shard-exact Philox noise (global-row keyed)" % world,
                        "world_size_observed": (dist.get_world_size() if distributed else 1),
-                       "collective_backend": (dist.get_backend() + " (RCCL)" if distributed else None),
+                       "collective_backend": ((dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else " (TEST ONLY: device tensors through the host)")) if distributed else None),
                        # attribution of a step (SCALE runs: a sub-linear point can be explained from this record): wall time per rank over the timed steps (ms per
                        # step, min / max over ranks), event-timed conditioning broadcast + shard slicing, event-timed sampler (graph replay or eager launches) on rank 0
-                       "per_rank_ms": rank_dts, "broadcast_ms": broadcast_ms if distributed else 0.0, "graph_replay_ms": replay_ms},
-            "roofline": roof, "cpu_baseline": cpu, "throughput": throughput, "fast_mode": fast_mode,
+                       "per_rank_ms": head["per_rank_ms"], "broadcast_ms": head["broadcast_ms"], "broadcast_mbytes": round(head["broadcast_bytes"] / 1e6, 3),
+                       "graph_replay_ms": head["sampler_ms"]},
+            "roofline": head["roofline"], "cpu_baseline": cpu, "best_256px_8step": best, "throughput": throughput, "fast_mode": fast_mode,
         }
+        if a.rehearsal:
+            line["rehearsal"] = dict(head.get("rehearsal", {}), note="TEST ONLY (--rehearsal): tiny model, small sizes -- exercises the N > 1 code paths, not a measurement")
+        if a.share_device:
+            line["config"]["share_device"] = True
         if hooks:
             line["test_hooks"] = hooks  # A/B run: NOT the product configuration
         print(json.dumps(line), flush=True)
