@@ -109,6 +109,23 @@ extern "C" int paella_probe_gemm_clock(unsigned long long* out2) {
 }
 #endif
 
+// Workgroups per CU a ring instantiation asks the register allocator for: the register-side wish (5 for the 3-stage 32x32 tile, 4 for the other one- and two-block
+// wave tiles, 3 for 64x64, 1 for the 8-wave tile) CAPPED by what its LDS footprint admits on a 160 KiB CU -- asking for more than LDS allows only shrinks the register
+// budget for nothing (twelve instantiations used to "fail to meet the occupancy target").  Mirrors the kernel's own LDS arithmetic (smem[] below);
+// tests/test_kernel_resources.py holds the compiler's numbers against it.
+constexpr int ring_lds_bytes(int WM, int WN, int TM, int TN, int APRO, int RING) {
+    const int BM = WM * TM * 16, BN = WN * TN * 16;
+    const bool big = WM * WN == 8;
+    const int aux = (big && APRO == 1) ? 576 : (APRO == 1 ? 512 : (APRO == 4 ? 320 : 0));
+    const int scr = big ? 0 : WM * WN * TN * 16;
+    return (RING * ((BM + BN) * 32 + aux) + 16 + scr) * 4;
+}
+constexpr int ring_wg_per_cu(int WM, int WN, int TM, int TN, int APRO, int RING) {
+    const int wish = WM * WN == 8 ? 1 : TM * TN == 1 ? (RING == 3 ? 5 : 4) : (TM * TN == 2 ? 4 : 3);
+    const int fit = (160 * 1024) / ring_lds_bytes(WM, WN, TM, TN, APRO, RING);
+    return fit < wish ? (fit < 1 ? 1 : fit) : wish;
+}
+
 template <int WM, int WN, int TM, int TN, int PD, int APRO, bool TAIL = false, int BK = 32, bool DMA = false, int RING = 0, bool BF = false>  // BK: K step (32 or 64 floats per LDS row); APRO: 0 none, 1 GRN scale/shift, 2 LayerNorm from row statistics; TAIL: fused sampling tail (head GEMM);
 // DMA: operands that need no transform (W always, A when APRO == 0) go global -> LDS directly (buffer_load ... lds), no staging registers, no ds_write pass
 // APRO 4 (ring tiles only): the GRN apply from the producer's UNFINISHED statistics -- a' = a * (1 + gamma * gx / (mean gx + 1e-6)) + shift, the mean
@@ -129,7 +146,7 @@ template <int WM, int WN, int TM, int TN, int PD, int APRO, bool TAIL = false, i
 // the LDS-DMA addressing, the ring, the stream-K decomposition, the slabs and every epilogue are shared with the fp32 instantiation: a lane's ds_read_b128 of
 // slot kk * 4 + kq holds k = kk * 32 + kq * 8 .. + 7 -- exactly its operand of ONE 16x16x32 MFMA where the fp32 kernel issues four 16x16x4 ones.  Only the
 // all-DMA variants exist (direct-to-LDS twins and ring tiles; prologues 0 and 2 -- the folded LayerNorm always takes the fold, there is no operand-side guard).
-__global__ __launch_bounds__(64 * WM * WN, RING > 0 ? (WM * WN == 8 ? 1 : TM * TN == 1 ? (RING == 3 ? 5 : 4) : (TM * TN == 2 ? 4 : 3))
+__global__ __launch_bounds__(64 * WM * WN, RING > 0 ? ring_wg_per_cu(WM, WN, TM, TN, APRO, RING)
                                            : (TAIL && DMA) ? 4  // fused head + tail on the 64x64 direct-to-LDS tile: four independent workgroups per CU
                                            : (TAIL && WM * WN == 8 && TM * TN == 4) ? 4  // fused head + tail on 128x64 tiles: TWO+ workgroups per CU, one's Philox / log epilogue overlaps another's main loop
                                            : (WM == 2 && WN == 2 && TM * TN == 1 && PD == 2 && BK == 32 && (APRO == 0 || APRO == 3)) ? 5  // (GRN / LayerNorm variants spill under 96 registers)
