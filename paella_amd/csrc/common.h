@@ -189,7 +189,8 @@ int launch_tail_finalize(const TailArgs& a, const float* part_score, const int* 
 static inline bool gemm_bf16_ok(int K, int lda, int ldw) { return K > 0 && (K & 63) == 0 && (lda & 7) == 0 && (ldw & 7) == 0; }
 
 // ln_stats [M, nblk, 2] (per 16-column block (sum, centred M2)) -> out4 [M, 4] = (mean, rstd, mean - (float)mean, |mean| * rstd)
-int launch_ln_rowstat_finalize(const float* stats, int nblk, int K, float eps, float* out4, int64_t M, hipStream_t stream);
+int launch_ln_rowstat_finalize(const float* stats, int nblk, int K, float eps, float* out4, int64_t M, const float* A32, unsigned short* A16, int lda, float ratio,
+                               unsigned* guard_count, hipStream_t stream);  // A16 != null: rows above `ratio` are rewritten as bf16(LayerNorm(fp32 row)) (bf16 fast mode)
 
 // LayerNorm over the channel dimension of [rows, C]; no learned affine (eps 1e-6),
 // optional scalar affine y = ln(x)*(1+g0)+g1 (VQGAN), optional space-to-depth gather:

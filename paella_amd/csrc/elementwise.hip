@@ -123,7 +123,12 @@ int launch_layernorm16(const float* x, float* y, unsigned short* y16, int64_t ro
 // (thousands of rows: every one of the N / 64 workgroups of a tile row would otherwise re-derive the same 64 rows in its ramp -- LayerNorm-consuming
 // GEMMs ran 8-10 % behind plain ones); the batch-1 launches keep the in-kernel derivation (an extra launch costs more than it saves there).
 // 16 lanes per row, fp64 combination, fixed order.
-__global__ __launch_bounds__(256) void ln_rowstat_finalize_kernel(const float* __restrict__ stats, int nblk, int K, float eps, f32x4* __restrict__ out, int64_t M) {
+// bf16 fast mode (A16 != null): a row whose |mean| / std exceeds `ratio` loses its digits in the bf16 COPY the consuming GEMM multiplies (the copy's rounding is
+// ratio * 2^-9 of a standard deviation per element and the folded LayerNorm cannot undo it) -- such a row of A16 is rewritten here as bf16((x - mean) * rstd) from
+// the fp32 row, and the consumer skips the fold for it (gemm_nt_kernel: ln_pre).  Ordinary activations never trip it (|mean| / std <= 0.07 in the model).
+__global__ __launch_bounds__(256) void ln_rowstat_finalize_kernel(const float* __restrict__ stats, int nblk, int K, float eps, f32x4* __restrict__ out, int64_t M,
+                                                                  const float* __restrict__ A32, unsigned short* __restrict__ A16, int lda, float ratio,
+                                                                  unsigned* __restrict__ guard_count) {
     const int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
     const int l16 = threadIdx.x & 15;
     if (row >= M) return;
@@ -132,16 +137,30 @@ __global__ __launch_bounds__(256) void ln_rowstat_finalize_kernel(const float* _
     for (int j = l16; j < nblk; j += 16) acc.add(st[2 * j], st[2 * j + 1]);
 #pragma unroll
     for (int o = 1; o < 16; o <<= 1) { acc.S += __shfl_xor(acc.S, o, 64); acc.Q += __shfl_xor(acc.Q, o, 64); acc.M += __shfl_xor(acc.M, o, 64); }
-    if (l16 == 0) {
-        float mu, rs;
-        acc.finish(K, eps, mu, rs);
-        out[row] = f32x4{mu, rs, (float)(acc.S / (double)K - (double)mu), fabsf(mu) * rs};
+    float mu, rs;
+    acc.finish(K, eps, mu, rs);  // (all 16 lanes hold the same totals after the butterfly)
+    const float mu_lo = (float)(acc.S / (double)K - (double)mu);
+    if (l16 == 0) out[row] = f32x4{mu, rs, mu_lo, fabsf(mu) * rs};
+    if (A16 && fabsf(mu) * rs > ratio) {
+        typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+        const float* src = A32 + (size_t)row * lda;
+        unsigned short* dst = A16 + (size_t)row * lda;
+        for (int k = l16 * 4; k < K; k += 64) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(src + k);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = ((v[e] - mu) - mu_lo) * rs;
+            *reinterpret_cast<bf16x4_t*>(dst + k) = __builtin_convertvector(v, bf16x4_t);
+        }
+        if (guard_count && l16 == 0) atomicAdd(guard_count, 1u);  // test hook only (null in the product)
     }
 }
 
-int launch_ln_rowstat_finalize(const float* stats, int nblk, int K, float eps, float* out4, int64_t M, hipStream_t st) {
+int launch_ln_rowstat_finalize(const float* stats, int nblk, int K, float eps, float* out4, int64_t M, const float* A32, unsigned short* A16, int lda, float ratio,
+                               unsigned* guard_count, hipStream_t st) {
     if (M <= 0) return PAELLA_OK;
-    hipLaunchKernelGGL(ln_rowstat_finalize_kernel, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, st, stats, nblk, K, eps, reinterpret_cast<f32x4*>(out4), M);
+    if (A16 && (!A32 || (K & 3) || (lda & 3))) { paella_set_error("ln_rowstat_finalize: the bf16 rewrite needs the fp32 rows and K, lda %% 4 == 0"); return PAELLA_ERR_ARG; }
+    hipLaunchKernelGGL(ln_rowstat_finalize_kernel, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, st, stats, nblk, K, eps, reinterpret_cast<f32x4*>(out4), M, A32, A16, lda, ratio,
+                       guard_count);
     LAUNCH_CHECK_RET();
     return PAELLA_OK;
 }

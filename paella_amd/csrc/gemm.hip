@@ -120,8 +120,9 @@ constexpr int ring_lds_bytes(int WM, int WN, int TM, int TN, int APRO, int RING)
     const int scr = big ? 0 : WM * WN * TN * 16;
     return (RING * ((BM + BN) * 32 + aux) + 16 + scr) * 4;
 }
-constexpr int ring_wg_per_cu(int WM, int WN, int TM, int TN, int APRO, int RING) {
-    const int wish = WM * WN == 8 ? 1 : TM * TN == 1 ? (RING == 3 ? 5 : 4) : (TM * TN == 2 ? 4 : 3);
+constexpr int ring_wg_per_cu(int WM, int WN, int TM, int TN, int APRO, int RING, bool BF) {
+    // (the bf16 64x32 tile with the operand-side LayerNorm guard needs > 128 registers: three workgroups per CU there instead of a spill)
+    const int wish = WM * WN == 8 ? 1 : TM * TN == 1 ? (RING == 3 ? 5 : 4) : (TM * TN == 2 ? ((BF && APRO == 2 && TM == 2) ? 3 : 4) : 3);
     const int fit = (160 * 1024) / ring_lds_bytes(WM, WN, TM, TN, APRO, RING);
     return fit < wish ? (fit < 1 ? 1 : fit) : wish;
 }
@@ -145,8 +146,8 @@ template <int WM, int WN, int TM, int TN, int PD, int APRO, bool TAIL = false, i
 // (v_mfma_f32_16x16x32_bf16, fp32 accumulation).  A K step is the same 128 BYTES per row (64 bf16 instead of 32 floats), so the LDS image, the XOR swizzle,
 // the LDS-DMA addressing, the ring, the stream-K decomposition, the slabs and every epilogue are shared with the fp32 instantiation: a lane's ds_read_b128 of
 // slot kk * 4 + kq holds k = kk * 32 + kq * 8 .. + 7 -- exactly its operand of ONE 16x16x32 MFMA where the fp32 kernel issues four 16x16x4 ones.  Only the
-// all-DMA variants exist (direct-to-LDS twins and ring tiles; prologues 0 and 2 -- the folded LayerNorm always takes the fold, there is no operand-side guard).
-__global__ __launch_bounds__(64 * WM * WN, RING > 0 ? ring_wg_per_cu(WM, WN, TM, TN, APRO, RING)
+// all-DMA variants exist (direct-to-LDS twins and ring tiles; prologues 0 and 2 -- the folded LayerNorm's operand-side guard re-reads flagged 16-row blocks from the fp32 tensor, see ln_fix).
+__global__ __launch_bounds__(64 * WM * WN, RING > 0 ? ring_wg_per_cu(WM, WN, TM, TN, APRO, RING, BF)
                                            : (TAIL && DMA) ? 4  // fused head + tail on the 64x64 direct-to-LDS tile: four independent workgroups per CU
                                            : (TAIL && WM * WN == 8 && TM * TN == 4) ? 4  // fused head + tail on 128x64 tiles: TWO+ workgroups per CU, one's Philox / log epilogue overlaps another's main loop
                                            : (WM == 2 && WN == 2 && TM * TN == 1 && PD == 2 && BK == 32 && (APRO == 0 || APRO == 3)) ? 5  // (GRN / LayerNorm variants spill under 96 registers)
@@ -319,7 +320,18 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? ring_wg_per_cu(WM, WN, TM,
     // the fold cancels when |mu| >> std (gemm_device.h: kLnFoldMaxRatio): such 16-row blocks normalise their operand FRAGMENTS instead (ln_fix) and skip the fold
     float fr_mu_lo[APRO == 2 ? TM : 1];  // mean - (float)mean: the operand-side form subtracts the mean in two pieces (an fp32 mean alone is off by eps * |mean|, i.e. eps * ratio in units of std)
     bool ln_dir[APRO == 2 ? TM : 1];
+    // bf16 operands, two regimes (the LDS image is the ROUNDED copy, so a flagged row needs its fp32 source): with the row pre-pass (GemmArgs::ln_row, >= 2048 rows
+    // and every 8-wave tile) launch_ln_rowstat_finalize has ALREADY rewritten the flagged rows of the bf16 copy as bf16(LayerNorm(row)) -- the main loop is untouched
+    // and the epilogue skips the fold per ROW (ln_pre, per lane); without it (batch-1 launches on the 4-wave tiles) flagged 16-row blocks re-read the fp32 rows in
+    // ln_fix.  The 8-wave bf16 tiles have no in-kernel fix (it spills there): the launcher always gives them the pre-pass.
+    constexpr bool BF_FIX = BF && APRO == 2 && NW == 4;
+    bool ln_pre[(APRO == 2 && BF) ? TM : 1];
+    auto ln_pre_row = [&](int i) __attribute__((always_inline)) -> bool {
+        if constexpr (APRO == 2 && BF) return ln_pre[i];
+        else return false;
+    };
     bool ln_any = false;
+    int ln_row0 = 0;  // first row of the (only) tile row this launch's LayerNorm statistics belong to
     const int ln_tile0 = ltile;
     auto ln_row_stats = [&]() __attribute__((always_inline)) {
         if constexpr (APRO == 2) {
@@ -327,14 +339,21 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? ring_wg_per_cu(WM, WN, TM,
             // block as a pair) and xor-reduce; combined in fp64 (RowStatAcc)
             int ln_tm, ln_tn;
             sk_tile_coords<(BM >= 64)>(p, ln_tile0, ln_tm, ln_tn);
+            ln_row0 = ln_tm * BM;
             if (g.ln_row) {  // finished once per row by launch_ln_rowstat_finalize (throughput regime): one 16-byte load per fragment row
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     const int gmc = min(ln_tm * BM + (wm * TM + i) * 16 + r16, g.M - 1);
                     const f32x4 v = *reinterpret_cast<const f32x4*>(g.ln_row + (size_t)gmc * 4);
                     fr_mu[i] = v[0]; fr_rs[i] = v[1]; fr_mu_lo[i] = v[2];
-                    ln_dir[i] = !BF && __builtin_amdgcn_ballot_w64(v[3] > g.ln_fold_ratio) != 0;
-                    ln_any = ln_any || ln_dir[i];
+                    if constexpr (BF) {
+                        ln_dir[i] = false;
+                        ln_pre[i] = g.A != nullptr && v[3] > g.ln_fold_ratio;  // this lane's row was normalised by the pre-pass: no fold for it
+                        ln_any = ln_any || __builtin_amdgcn_ballot_w64(ln_pre[i]) != 0;  // (test counter only)
+                    } else {
+                        ln_dir[i] = __builtin_amdgcn_ballot_w64(v[3] > g.ln_fold_ratio) != 0;
+                        ln_any = ln_any || ln_dir[i];
+                    }
                 }
                 if (g.ln_guard_count && ln_any && lane_k == 0) atomicAdd(g.ln_guard_count, 1u);  // test hook only (null in the product)
                 return;
@@ -366,18 +385,40 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? ring_wg_per_cu(WM, WN, TM,
                 acc.S += __shfl_xor(acc.S, 32, 64); acc.Q += __shfl_xor(acc.Q, 32, 64); acc.M += __shfl_xor(acc.M, 32, 64);
                 acc.finish(g.K, g.ln_eps, fr_mu[i], fr_rs[i]);
                 fr_mu_lo[i] = (float)(acc.S / (double)g.K - (double)fr_mu[i]);
-                ln_dir[i] = !BF && __builtin_amdgcn_ballot_w64(fabsf(fr_mu[i]) * fr_rs[i] > g.ln_fold_ratio) != 0;  // wave-uniform, a function of the block's 16 rows only
+                ln_dir[i] = (!BF || (BF_FIX && g.A != nullptr)) && __builtin_amdgcn_ballot_w64(fabsf(fr_mu[i]) * fr_rs[i] > g.ln_fold_ratio) != 0;  // wave-uniform, a function of the block's 16 rows only
+                if constexpr (BF) ln_pre[i] = false;
                 ln_any = ln_any || ln_dir[i];
             }
             if (g.ln_guard_count && ln_any && lane_k == 0) atomicAdd(g.ln_guard_count, 1u);  // test hook only (null in the product)
         }
     };
     // operand-side LayerNorm of an A fragment (row block i, 4 consecutive k from kbase) -- only for blocks flagged by ln_row_stats; zero past K like the staged K tail
+    // BF (bf16 operands): the LDS image holds the operand ALREADY ROUNDED to bf16 -- at |mu| / std = r that rounding is r * 2^-9 of a standard deviation per element
+    // (2-3 % at r = 16, 20-30 % at r = 160: ADVICE r05), and no arithmetic on the rounded value brings it back.  A flagged block therefore re-reads its rows from
+    // the fp32 residual stream (GemmArgs::A, the tensor the bf16 copy was made from), normalises in fp32 and rounds the NORMALISED value to bf16: the error is the
+    // ordinary 2^-9 of a unit-scale operand again.  kbase counts fp32 K steps like the callers' LDS slots: the fragment's 8 consecutive k start at 2 * kbase.
+    // 16 lanes x 32 B per row and fragment, uncoalesced and straight from L2 / HBM: slow, and only ever executed by flagged blocks.
     auto ln_fix = [&](f32x4& a, int i, int kbase) __attribute__((always_inline)) {
         if constexpr (APRO == 2 && !BF) {
             if (ln_dir[i]) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) a[e] = (kbase + e < g.K) ? ((a[e] - fr_mu[i]) - fr_mu_lo[i]) * fr_rs[i] : 0.f;
+            }
+        }
+        if constexpr (BF_FIX) {
+            if (ln_dir[i]) {
+                const int gm = min(ln_row0 + (wm * TM + i) * 16 + r16, g.M - 1);
+                const float* src = g.A + (size_t)gm * g.lda + 2 * kbase;
+                typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+                f32x4 v = *reinterpret_cast<const f32x4*>(src);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = ((v[e] - fr_mu[i]) - fr_mu_lo[i]) * fr_rs[i];
+                const bf16x4_t lo = __builtin_convertvector(v, bf16x4_t);
+                v = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = ((v[e] - fr_mu[i]) - fr_mu_lo[i]) * fr_rs[i];
+                const bf16x4_t hi = __builtin_convertvector(v, bf16x4_t);
+                a = __builtin_bit_cast(f32x4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
             }
         }
     };
@@ -677,7 +718,7 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? ring_wg_per_cu(WM, WN, TM,
                 if (ok) {
                     f32x4 a = acc[i][j];
                     if constexpr (APRO == 2) {
-                        if (!ln_dir[i]) a = (a - *reinterpret_cast<const f32x4*>(g.ln_wsum + nn) * fr_mu[i]) * fr_rs[i];  // the folded LayerNorm (see ln_row_stats)
+                        if (!(ln_dir[i] || ln_pre_row(i))) a = (a - *reinterpret_cast<const f32x4*>(g.ln_wsum + nn) * fr_mu[i]) * fr_rs[i];  // the folded LayerNorm (see ln_row_stats)
                     }
                     v = epilogue_apply<BF>(g.ep, g.N, m, nn, a);
                     epilogue_write(g.ep, g.C, g.ldc, m, nn, v);
@@ -863,7 +904,7 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? ring_wg_per_cu(WM, WN, TM,
                 }
             }
         };
-        auto compute_ring = [&](int cs) __attribute__((always_inline)) {
+        auto compute_ring = [&](int cs, int kt_ring) __attribute__((always_inline)) {
             const float* As = smem + cs * STAGE_FLOATS;
             const float* Bs = As + BM * BK;
             f32x4 af[KG][TM], bf[KG][TN];
@@ -881,11 +922,11 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? ring_wg_per_cu(WM, WN, TM,
                     bf[kk][j] = *reinterpret_cast<const f32x4*>(Bs + row * BK + ((c4 ^ (row & (SL - 1))) << 2));
                 }
             }
-            if (APRO == 2 && ln_any) {  // (K % 32 == 0 on ring tiles: no K tail to mask)
+            if (APRO == 2 && ln_any) {  // (K % 32 == 0 on ring tiles: no K tail to mask; the bf16 form needs the fragment's K position)
 #pragma unroll
                 for (int kk = 0; kk < KG; ++kk)
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) ln_fix(af[kk][i], i, 0);
+                    for (int i = 0; i < TM; ++i) ln_fix(af[kk][i], i, BF_FIX ? kt_ring * BK + (kk * 4 + kq) * 4 : 0);
             }
             if (APRO == 1) {  // GlobalResponseNorm apply on the fragments: a' = a * scale[sample][k] + shift[k] (same expression as the staged form)
                 const float* X = Bs + BN * BK;
@@ -997,7 +1038,7 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? ring_wg_per_cu(WM, WN, TM,
                     for (int i = 0; i < TM; ++i) Sg[kk][i] = *reinterpret_cast<const f32x4*>(X + 64 + sidx[i] * 32 + c4 * 4);
                 }
             };
-            auto big_xform = [&](auto kk_tag) __attribute__((always_inline)) {  // GlobalResponseNorm apply on the fragments: a' = a * scale[sample][k] + shift[k]
+            auto big_xform = [&](auto kk_tag, int kt_ring) __attribute__((always_inline)) {  // GlobalResponseNorm apply on the fragments: a' = a * scale[sample][k] + shift[k]
                 constexpr int kk = decltype(kk_tag)::value;
                 if constexpr (APRO == 1) {
 #pragma unroll
@@ -1034,7 +1075,7 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? ring_wg_per_cu(WM, WN, TM,
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     if (pend) {
-                        big_xform(I1{});
+                        big_xform(I1{}, ckt + s2 - 1);  // k group 1 of the PREVIOUS unit
                         mfma_group(I1{}, I0{}, I4{});
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -1046,14 +1087,14 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? ring_wg_per_cu(WM, WN, TM,
                     __builtin_amdgcn_sched_barrier(0);
                     big_read(I1{}, cs);
                     __builtin_amdgcn_sched_barrier(0);
-                    big_xform(I0{});
+                    big_xform(I0{}, ckt + s2);
                     mfma_group(I0{}, I0{}, I4{});
                     __builtin_amdgcn_sched_barrier(0);
                     pend = true;
                     cs = cs + 1 == RING ? 0 : cs + 1;
                     ls = ls + 1 == RING ? 0 : ls + 1;
                 }
-                big_xform(I1{});
+                big_xform(I1{}, ckt + seg_len - 1);
                 mfma_group(I1{}, I0{}, I4{});
                 __builtin_amdgcn_sched_barrier(0);
                 if (i + seg_len == n) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may still be landing when the workgroup's LDS is released
@@ -1079,7 +1120,7 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? ring_wg_per_cu(WM, WN, TM,
                 asm volatile("" ::: "memory");
                 fetch_ring(ls);
                 __builtin_amdgcn_sched_barrier(0);
-                compute_ring(cs);
+                compute_ring(cs, ckt + s2);
                 __builtin_amdgcn_sched_barrier(0);
                 cs = cs + 1 == RING ? 0 : cs + 1;
                 ls = ls + 1 == RING ? 0 : ls + 1;
@@ -1720,16 +1761,25 @@ static int launch_gemm_cfg_impl(const GemmArgs& g_in, int cfg, int splitk, void*
     }
     const bool have_ws = ws && ws_bytes > kGemmTicketBytes;
     size_t slab_cap = have_ws ? ws_bytes - kGemmTicketBytes : 0;
-    if (g.ln_stats && !g.ln_row && g.M >= kLnPrepassMinRows && slab_cap >= ((size_t)80 << 20) + (size_t)g.M * 16) {
+    // The LayerNorm row pre-pass: statistics finished once per row.  bf16 operands: the same launch rewrites the rows of the bf16 copy whose |mean| / std exceeds
+    // the fold threshold as bf16(LayerNorm(fp32 row)) (the consumer then skips the fold for them: gemm_nt_kernel, ln_pre).
+    auto ln_prepass = [&]() -> int {
         // the finished statistics live at the END of the split-K region (the slabs of this launch, if any, start at its front); the carve-out is aligned down
         // whatever ws_bytes the caller passed, and only taken when >= 80 MiB of slab space remain (the largest launch shape, 256 ranges of 256x128 tiles, needs 64)
         const size_t bytes = ((size_t)g.M * 16 + 255) & ~(size_t)255;
         const size_t row4_off = (ws_bytes - bytes) & ~(size_t)255;
         float* row4 = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + row4_off);
         slab_cap = row4_off - kGemmTicketBytes;
-        const int rc = launch_ln_rowstat_finalize(g.ln_stats, g.ln_nblk, g.K, g.ln_eps, row4, g.M, st);
+        const int rc = launch_ln_rowstat_finalize(g.ln_stats, g.ln_nblk, g.K, g.ln_eps, row4, g.M, bf ? g.A : nullptr, bf ? const_cast<unsigned short*>(g.A16) : nullptr, g.lda,
+                                                  g_ln_fold_ratio.load(std::memory_order_relaxed), g_ln_guard_count.load(std::memory_order_relaxed), st);
         if (rc != PAELLA_OK) return rc;
         g.ln_row = row4;
+        return PAELLA_OK;
+    };
+    const bool prepass_fits = slab_cap >= ((size_t)80 << 20) + (size_t)g.M * 16;
+    if (g.ln_stats && !g.ln_row && g.M >= kLnPrepassMinRows && prepass_fits) {
+        const int rc = ln_prepass();
+        if (rc != PAELLA_OK) return rc;
     }
     unsigned G = 0;
     if (cfg < 0 && bf) {
@@ -1745,6 +1795,11 @@ static int launch_gemm_cfg_impl(const GemmArgs& g_in, int cfg, int splitk, void*
     }
     const TileCfg& tc = kCfgs[cfg];
     const int BM = tc.wm * tc.tm * 16, BN = tc.wn * tc.tn * 16;
+    if (bf && g.ln_stats && g.A && !g.ln_row && tc.wm * tc.wn == 8) {  // the 8-wave bf16 tiles have no in-kernel operand-side guard: the pre-pass it is, whatever M
+        if (!prepass_fits) { paella_set_error("gemm: a bf16 LayerNorm-consuming launch on an 8-wave tile needs a workspace (>= 80 MiB + 16 bytes per row) for the row pre-pass"); return PAELLA_ERR_WORKSPACE; }
+        const int rc = ln_prepass();
+        if (rc != PAELLA_OK) return rc;
+    }
     if (bf && !bf16_cfg(cfg)) { paella_set_error("gemm: tile config %d has no bf16-operand variant (10, 18, 19, 30..36 do)", cfg); return PAELLA_ERR_ARG; }
     if ((g.grn_gx || g.ep.grn_gx_out) && (!tc.ring || tc.wm * tc.wn == 8)) { paella_set_error("gemm: the in-epilogue / on-load GRN statistics need a ring tile (got tile %d)", cfg); return PAELLA_ERR_STATE; }
     if (g.grn_gx && (!g.grn_gamma || !g.a_shift || !g.grn_part || g.grn_np <= 0 || g.a_scale || g.ln_stats || g.a_rows_per_sample % 16)) {

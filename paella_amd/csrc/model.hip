@@ -1184,6 +1184,19 @@ extern "C" int paella_test_gemm_bf16(const unsigned short* A16, const unsigned s
     }
     return launch_gemm_cfg(g, tile_cfg, splitk, ws, ws_bytes, (hipStream_t)stream);
 }
+// test hook (test_hooks.h): the LayerNorm-folding bf16 GEMM as the model launches it -- bf16 copy A16 of the fp32 rows A32, statistics of the fp32 rows, and the
+// fp32 rows themselves for the operand-side guard (blocks with |mean| / std above the fold threshold re-read and normalise them: gemm.hip, ln_fix)
+extern "C" int paella_test_gemm_bf16_ln(const unsigned short* A16, const float* A32, const unsigned short* W16, float* C, int M, int N, int K, const float* ln_stats,
+                                        int tile_cfg, int splitk, void* ws, size_t ws_bytes, void* stream) {
+    if (!ln_stats) { paella_set_error("gemm_bf16_ln: statistics required"); return PAELLA_ERR_ARG; }
+    GemmArgs g = gemm_args(A32, K, nullptr, K, C, N, M, N, K);
+    g.A16 = A16; g.W16 = W16;
+    static DevBuf wsum;
+    if (wsum.n < (size_t)N) RET_IF(devbuf_alloc(wsum, (size_t)N));
+    RET_IF(launch_rowsum_bf16(W16, wsum.p, N, K, (hipStream_t)stream));
+    g.ln_stats = ln_stats; g.ln_nblk = K / 16; g.ln_eps = 1e-6f; g.ln_wsum = wsum.p;
+    return launch_gemm_cfg(g, tile_cfg, splitk, ws, ws_bytes, (hipStream_t)stream);
+}
 extern "C" int paella_op_layernorm(const float* x, float* y, int64_t rows, int C, float eps, void* stream) {
     return launch_layernorm(x, y, rows, C, eps, 1.f, 0.f, 0, 0, 0, (hipStream_t)stream);
 }

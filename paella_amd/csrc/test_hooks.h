@@ -13,6 +13,10 @@ extern "C" {
  * [M, K/16, 2] (sum, centred M2) partials; C16 != NULL: also store the result rounded to bf16 (C may then be NULL) */
 int paella_test_gemm_bf16(const unsigned short* A16, const unsigned short* W16, const float* bias, const float* residual, float* C, unsigned short* C16,
                           int M, int N, int K, int act, const float* ln_stats, int tile_cfg, int splitk, void* ws, size_t ws_bytes, void* stream);
+/* the LayerNorm-folding bf16 GEMM as the model launches it: A16 = the bf16 copy of the fp32 rows A32, ln_stats = [M, K/16, 2] partials of the fp32 rows; blocks whose
+ * |mean| / std exceeds the fold threshold (paella_test_ln_fold_ratio) re-read A32, normalise in fp32 and round the normalised operand to bf16 */
+int paella_test_gemm_bf16_ln(const unsigned short* A16, const float* A32, const unsigned short* W16, float* C, int M, int N, int K, const float* ln_stats,
+                             int tile_cfg, int splitk, void* ws, size_t ws_bytes, void* stream);
 /* the bf16 attention core of the opt-in fast mode (>= 256 queries in the model): q16 / ks16 / vs16 bf16 [B*L, nhead*D], conditioning k / v fp32, out16 bf16 */
 int paella_test_attention_bf16(const unsigned short* q16, const unsigned short* ks16, const unsigned short* vs16, const float* k_cond, const float* v_cond,
                                unsigned short* out16, int B, int nhead, int D, int Lq, int Lself, int Lcond, const float* key_weights, int n_kw, void* stream);

@@ -197,7 +197,7 @@ def test_bf16_forward_deviation_and_restore(built_lib, cfg_name, B, grid):
     assert torch.isfinite(fast).all()
     assert not torch.equal(fast, exact)          # the fast path really ran
     assert torch.equal(fast, fast2)              # and is run-to-run deterministic
-    assert diff <= 0.25 * max(1.0, std) and flips <= 0.15
+    assert diff <= 0.08 * max(1.0, std) and flips <= 0.03   # measured 0.02-0.033 std / 0.7-1.4 %: a regression to 10 % flips must fail
     assert torch.equal(again, exact)             # and the exact path is back, bit for bit
 
 
@@ -274,3 +274,108 @@ def test_bf16_attention_core(built_lib, B, nh, D, Lq, Ls, Lc, nkw):
     err = (out.float().cpu() - ref).abs().max().item()
     print("bf16 attention core B=%d heads=%d D=%d Lq=%d Lk=%d: max |err| %.2e on outputs of std %.2f" % (B, nh, D, Lq, Ls + Lc, err, ref.std().item()))
     assert torch.isfinite(out.float()).all() and err <= 6e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The operand-side LayerNorm guard of the bf16 LayerNorm-folding GEMM.  The fold multiplies the bf16 COPY of the residual stream; at
+# |row mean| / std = r the copy's rounding is r * 2^-9 of a standard deviation per element, which no epilogue arithmetic can undo.  16-row blocks above the
+# fold threshold therefore re-read the fp32 rows, normalise in fp32 and round the NORMALISED operand to bf16 (gemm.hip: ln_fix, BF form).
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tile,splitk", [(10, 1), (18, 1), (18, 2), (19, 1), (30, 1), (30, 5), (31, 1), (31, 2), (32, 1), (33, 1), (34, 1), (35, 1), (35, 3), (36, 1), (36, 2), (-1, 1)])
+def test_bf16_gemm_layernorm_guard_every_tile(built_lib, tile, splitk):
+    """Rows 0..79 have |mean| / std = 160 (five flagged 16-row blocks), the rest ~0.2 (fold).  Reference, in fp64: flagged blocks = bf16(LayerNorm(A)) . W16^T,
+    the others = the fold on the rounded operand; every K position of every tile x work split must hit the right fp32 elements (asymmetric operands)."""
+    lib = built_lib
+    M, N, K = 216, 168, 448
+    g = torch.Generator().manual_seed(tile * 13 + splitk)
+    A = torch.randn(M, K, generator=g) * 1.5 + 0.3 + torch.arange(K)[None, :] * 0.004
+    A[:80] += 240.0 + torch.arange(80)[:, None] * 0.5
+    W = torch.randn(N, K, generator=g) / K ** 0.5 + torch.arange(N)[:, None] * 0.001
+    stats = _ln_partials(A.view(M, K // 16, 16)).to(DEV)
+    A16, W16 = A.bfloat16(), W.bfloat16()
+    mu = A.double().mean(1, keepdim=True)
+    rstd = 1.0 / torch.sqrt(A.double().var(1, unbiased=False, keepdim=True) + 1e-6)
+    ratio = (mu.abs() * rstd).view(-1)
+    assert ratio[:80].min() > 100 and ratio[80:].max() < 1.0
+    ln = (A.double() - mu) * rstd
+    ref = torch.where(torch.arange(M)[:, None] < 80, ln.float().bfloat16().double() @ W16.double().t(), ((A16.double() - mu) * rstd) @ W16.double().t()).float()
+    exact = (ln @ W.double().t()).float()     # what fp32 LayerNorm + fp32 GEMM gives
+    A16d, A32d, W16d = A16.to(DEV), A.to(DEV), W16.to(DEV)
+    ws = _lib.new_workspace(128 << 20, DEV)
+    counter = torch.zeros(1, dtype=torch.int32, device=DEV)
+    lib.paella_test_ln_guard_counter(ctypes.c_void_p(counter.data_ptr()))
+    try:
+        C = torch.full((M, N), float("nan"), device=DEV)
+        rc = lib.paella_test_gemm_bf16_ln(_p(A16d), _p(A32d), _p(W16d), _p(C), M, N, K, _p(stats), tile, splitk, _p(ws), ws.numel(), _st())
+        assert rc == 0, lib.paella_last_error()
+        torch.cuda.synchronize()
+    finally:
+        lib.paella_test_ln_guard_counter(None)
+    assert int(counter.item()) > 0, "no wave took the operand-side path"
+    # unflagged rows: the fold on the rounded operand, as test_bf16_gemm_layernorm_fold.  Flagged rows: the device normalises in fp32, the reference in fp64 -- where
+    # the two land on different sides of a bf16 rounding boundary ONE operand moves by an ulp (2^-7 at |value| in [2, 4)) times |w| <= 0.25: whole-row shifts of up
+    # to ~4e-3 were measured; 1e-2 is still 250x below what the unguarded fold loses (>= 2.5)
+    np.testing.assert_allclose(C.cpu().numpy()[80:], ref.numpy()[80:], atol=2e-3, rtol=2e-5)
+    np.testing.assert_allclose(C.cpu().numpy()[:80], ref.numpy()[:80], atol=1e-2, rtol=2e-5)
+    guarded = (C.cpu() - exact)[:80].abs().max().item()
+    # the same launch WITHOUT the fp32 rows (the pre-r06 behaviour: fold on the rounded copy): the flagged rows lose their digits
+    C0 = torch.full((M, N), float("nan"), device=DEV)
+    A16d = A16.to(DEV)   # a fresh copy: on the pre-pass path (8-wave tiles) the guarded launch has rewritten the flagged rows of its bf16 operand in place
+    assert lib.paella_test_gemm_bf16(_p(A16d), _p(W16d), None, None, _p(C0), None, M, N, K, 0, _p(stats), tile, splitk, _p(ws), ws.numel(), _st()) == 0
+    torch.cuda.synchronize()
+    unguarded = (C0.cpu() - exact)[:80].abs().max().item()
+    if tile in (30, 36, -1) and splitk == 1:
+        print("bf16 LayerNorm-folding GEMM, rows with |mean| / std = 160, tile %d: max |out - fp32 LayerNorm GEMM| %.3e with the guard, %.3e without (outputs of unit scale)" % (tile, guarded, unguarded))
+    assert guarded <= 0.05 and unguarded > 20 * guarded   # (0.02-0.033 measured: the ordinary bf16 operand rounding of a K = 448 contraction with |w| up to 0.25)
+    assert torch.equal(C[80 + 16:], C0[80 + 16:])   # rows of unflagged blocks are untouched by the guard
+
+
+@pytest.mark.parametrize("B,grid", [(1, 16), (2, 64)])
+@pytest.mark.parametrize("shift", [100.0, 1000.0])
+def test_bf16_layernorm_guard_inside_the_network(built_lib, B, grid, shift):
+    """The fast-mode twin of tests/test_gpu_unet.py::test_layernorm_guard_inside_the_network: TimestepBlock shifts push the rows every LayerNorm consumer
+    normalises to |mean| / std ~ 16 (shift 100) and ~ 160 (shift 1000).  With the guard the fast mode's deviation from the exact path stays at its ordinary
+    level (STATED BOUND: max |logit diff| <= 0.06 std, argmax flips <= 3 %); the same forward with the guard switched off (threshold hook at inf) is printed next to it."""
+    lib = built_lib
+    cfg = G.UNET_MID
+    m = paella_amd.Paella(**cfg)
+    sd = weights_for(m, sum(cfg["blocks"]))
+    for k in list(sd):
+        if k.endswith(".mapper.weight") and sd[k].dim() == 2 and sd[k].shape[1] == cfg["c_r"]:
+            c = sd[k].shape[0] // 2
+            sd[k] = sd[k] * 0.05
+            b = sd[k[:-6] + "bias"].clone()
+            b[:c] *= 0.1
+            b[c:] += shift
+            b[c + 3] += 60.0
+            b[c + c // 2 + 1] -= 45.0
+            b[2 * c - 5] += 80.0
+            sd[k[:-6] + "bias"] = b
+    m.load_state_dict(sd)
+    m = m.to(DEV)
+    g = torch.Generator().manual_seed(17)
+    x = torch.randint(0, cfg["num_labels"], (B, grid, grid), generator=g).to(DEV)
+    r = torch.rand(B, generator=g).to(DEV)
+    c = to_dev(cond_for(cfg, B, 3, 0, G.COND_SEED + 3), DEV)
+    exact = m(x, r, **c).clone()
+    m.set_gemm_precision("bf16")
+    counter = torch.zeros(1, dtype=torch.int32, device=DEV)
+    lib.paella_test_ln_guard_counter(ctypes.c_void_p(counter.data_ptr()))
+    try:
+        fast = m(x, r, **c).clone()
+        torch.cuda.synchronize()
+        n_guard = int(counter.item())
+        lib.paella_test_ln_fold_ratio(float("inf"))
+        unguarded = m(x, r, **c).clone()
+    finally:
+        lib.paella_test_ln_fold_ratio(4.0)
+        lib.paella_test_ln_guard_counter(None)
+        m.set_gemm_precision("fp32")
+    f1, d1, std = _flip_report(exact, fast)
+    f0, d0, _ = _flip_report(exact, unguarded)
+    print("bf16 fast mode, TimestepBlock shift %g, B=%d grid %d: %d waves took the operand-side LayerNorm; vs the exact path: max|logit diff| %.3e / flips %.4f with the guard, "
+          "%.3e / %.4f without (logit std %.3f)" % (shift, B, grid, n_guard, d1, f1, d0, f0, std))
+    assert n_guard > 0
+    assert d1 <= 0.06 * max(1.0, std) and f1 <= 0.03
+    # (what the guard buys INSIDE this network is printed, not asserted -- 1.2e-2 / 1.2 % against 1.8e-2 / 2.0 % at shift 1000: only the rows of three LayerNorm
+    # consumers per level are affected; the kernel-level test above shows the unguarded fold losing its digits outright, 4.1 against 0.03)
