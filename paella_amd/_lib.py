@@ -108,6 +108,7 @@ TEST_HOOKS = {
     "paella_test_gemm_ring": (c_int, [c_int]),
     "paella_test_ring_resident": (ctypes.c_long, [c_int, c_int]),
     "paella_test_gemm_site": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "paella_test_gemm_site_cfg": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "paella_test_gemm_big_stagger": (c_int, [c_int]),
     "paella_test_grn_fuse": (c_int, [c_int]),
     "paella_test_ln_fold_ratio": (c_int, [c_float]),

@@ -1444,7 +1444,7 @@ static long ring_resident(int cfg, int apro) {
 // Per-launch-site workgroup counts of the skinny (ring-tile) class: the rules below are global fits; a site (M, N, K, operand prologue class, bf16) listed here takes
 // its own count instead.  Entries come from tools/site_tune.py -- coordinate descent over every distinct site of the batch-1 image INSIDE the captured graph,
 // two passes, same box (profiles/r05_site_tune_b1.txt) -- and can be overridden at run time through the test hook (what the tuner itself uses).
-struct SiteG { int M, N, K, apro, bf, G; };
+struct SiteG { int M, N, K, apro, bf, G, cfg; };  // cfg: 0 = the rule's tile (only G is overridden; skinny ring class), > 0 = this tile id + 1 (any class)
 static SiteG g_sites[96] = {
     // profiles/r05_site_tune_b1.txt: 27 skinny sites of the batch-1 image swept, 5 moved (22.47 -> 22.24 ms per image on the tuning box, -1.0 %; the second pass changed
     // nothing); everywhere else the global rules sit within 30 us per image of the best candidate
@@ -1464,24 +1464,35 @@ static int count_builtin_sites() {
 }
 static const int g_nsites_builtin = count_builtin_sites();
 static std::atomic<int> g_nsites{g_nsites_builtin};
-static int site_lookup(int M, int N, int K, int apro, int bf) {
+static const SiteG* site_find(int M, int N, int K, int apro, int bf) {
     const int n = g_nsites.load(std::memory_order_acquire);
     for (int i = n - 1; i >= 0; --i)  // (later entries -- run-time overrides -- win)
-        if (g_sites[i].M == M && g_sites[i].N == N && g_sites[i].K == K && g_sites[i].apro == apro && g_sites[i].bf == bf) return g_sites[i].G;
-    return 0;
+        if (g_sites[i].M == M && g_sites[i].N == N && g_sites[i].K == K && g_sites[i].apro == apro && g_sites[i].bf == bf) return &g_sites[i];
+    return nullptr;
+}
+static int site_lookup(int M, int N, int K, int apro, int bf) {  // workgroup count of a skinny-class site (entries that also name a tile are handled by the caller)
+    const SiteG* e = site_find(M, N, K, apro, bf);
+    return (e && e->cfg == 0) ? e->G : 0;
 }
 // test hook: G > 0 sets / overrides a site, G == 0 removes the run-time entries of that site, M == 0 removes every run-time entry
-extern "C" int paella_test_gemm_site(int M, int N, int K, int apro, int bf, int G) {
+static int site_set(int M, int N, int K, int apro, int bf, int G, int cfg1);
+extern "C" int paella_test_gemm_site(int M, int N, int K, int apro, int bf, int G) { return site_set(M, N, K, apro, bf, G, 0); }
+// the same with an explicit tile id (any class; what tools/site_tune_mid.py sweeps): cfg < 0 = only the workgroup count
+extern "C" int paella_test_gemm_site_cfg(int M, int N, int K, int apro, int bf, int cfg, int G) {
+    if (cfg >= kNumCfgs) { paella_set_error("bad tile config %d", cfg); return PAELLA_ERR_ARG; }
+    return site_set(M, N, K, apro, bf, G, cfg < 0 ? 0 : cfg + 1);
+}
+static int site_set(int M, int N, int K, int apro, int bf, int G, int cfg1) {
     int n = g_nsites.load();
     if (M == 0) { g_nsites = g_nsites_builtin; return PAELLA_OK; }
     for (int i = n - 1; i >= g_nsites_builtin; --i)
         if (g_sites[i].M == M && g_sites[i].N == N && g_sites[i].K == K && g_sites[i].apro == apro && g_sites[i].bf == bf) {
-            if (G > 0) { g_sites[i].G = G; return PAELLA_OK; }
+            if (G > 0) { g_sites[i].G = G; g_sites[i].cfg = cfg1; return PAELLA_OK; }
             g_sites[i] = g_sites[n - 1]; g_nsites = n - 1; return PAELLA_OK;
         }
     if (G <= 0) return PAELLA_OK;
     if (n >= 96) { paella_set_error("site table full"); return PAELLA_ERR_STATE; }
-    g_sites[n] = SiteG{M, N, K, apro, bf, G};
+    g_sites[n] = SiteG{M, N, K, apro, bf, G, cfg1};
     g_nsites.store(n + 1, std::memory_order_release);
     return PAELLA_OK;
 }
@@ -1497,7 +1508,12 @@ static void choose_config(int M, int N, int K, int apro, bool ring_allowed, int 
     const long T128 = tiles_of_cfg(10, M, N), T64 = tiles_of_cfg(18, M, N), T32 = tiles_of_cfg(5, M, N);
     int cfg;
     long G;
-    if (T128 >= 1024) {
+    const SiteG* const site = site_find(M, N, K, apro, 0);
+    if (site && site->cfg > 0 && (!kCfgs[site->cfg - 1].ring || ring_allowed)) {
+        // a launch site with its own (tile, workgroup count): fitted inside the captured batch-32 graph (tools/site_tune_mid.py, profiles/r06_site_tune_mid_b32.txt)
+        cfg = site->cfg - 1;
+        G = site->G;
+    } else if (T128 >= 1024) {
         // plain operands: 64x64 tiles, 4 independent workgroups per CU, grouped rasterisation (140 TFLOP/s on 32768x5120x1280);
         // with a prologue the 8-wave 128x128 tile stages the A operand half as often and ties or wins
         // (a LayerNorm-consuming GEMM multiplies the raw operand since round 3 -- the normalisation is folded into its epilogue -- and takes the plain rule:
@@ -1506,6 +1522,11 @@ static void choose_config(int M, int N, int K, int apro, bool ring_allowed, int 
         else { cfg = 10; G = T128; }
     } else if (macs >= 2.5e9) {
         if ((K <= 768 || apro == 2) && T64 >= 1024) { cfg = 18; G = T64; }  // (LayerNorm-folded GEMMs: one statistics pass per workgroup -> one tile per workgroup)
+        // plain operands: the mid-size sweep INSIDE the batch-32 model (tools/site_tune_mid.py, profiles/r06_site_tune_mid_b32.txt: 18 sites x 4 tiles x workgroup counts)
+        // put the 64x64 direct-to-LDS tile 3-8 % ahead of 256 persistent 128x128 workgroups on every plain site of this class -- one tile per workgroup from 2048
+        // tiles up, 1024 balanced ranges below (4096x1280x1280 124 -> 116 us, 1024x5120x1280 121 -> 116, 2048x5120x1280 221 -> 211, 8192x640x1024 102 -> 94);
+        // with a GRN / LayerNorm prologue the old rule stays within 1 % of the best candidate.  Worth 0.5 % per image at batch 32: the class is closed.
+        else if (apro == 0) { cfg = 18; G = T64 >= 2048 ? T64 : 1024; }
         else { cfg = 10; G = 256; }
     } else if (g_gemm_ring && ring_allowed && macs >= 1.2e9 && macs < 2.4e9 && T64 < 1024 && apro != 2) {
         // 1.2-2.4 GFLOP with few tiles (256x5120x1280, 1024x1280x1280, ...): the 32x32 ring tile on every resident slot is 8-12 % ahead of 64x64 tiles

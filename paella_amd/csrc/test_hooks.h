@@ -44,6 +44,8 @@ int paella_test_gemm_ring(int cfg);
 /* per-launch-site workgroup count of the skinny (ring-tile) GEMM class: site = (M, N, K, prologue class 0 / 1 GRN / 2 LayerNorm, bf16 operands 0 / 1); G > 0 sets it,
  * G == 0 removes the site's run-time entry, M == 0 removes all run-time entries (tools/site_tune.py) */
 int paella_test_gemm_site(int M, int N, int K, int apro, int bf, int G);
+/* the same with an explicit tile id for sites of ANY class (cfg < 0: workgroup count only) */
+int paella_test_gemm_site_cfg(int M, int N, int K, int apro, int bf, int cfg, int G);
 /* the launch heuristic's table of resident workgroups (whole chip) of ring tile cfg (30..35) with operand prologue class apro (0 none, 1 GRN, 2 LayerNorm); -1 otherwise */
 long paella_test_ring_resident(int cfg, int apro);
 /* tile of the fused head GEMM + sampling tail: 9 = 128x128, 14 = 128x64 on 8 waves (several workgroups per CU), 18 = 64x64 direct-to-LDS (four workgroups per CU; default) */
