@@ -234,6 +234,12 @@ def test_1b_config5_geometry_128x128_s264_vs_oracle(built_lib):
     _real_geometry_vs_oracle(G.UNET_1B, 128, 256, 1, 14, "1B 128x128 S=264 (configs[4] geometry)")
 
 
+def test_1b_largest_key_count_128x128_s776_vs_oracle(built_lib):
+    """The corner VERDICT r05 named as untested: configs[4]'s grid (128x128 tokens) with configs[3]'s conditioning length (ByT5 768 + CLIP text + CLIP image =
+    776 rows) -- the largest key count of any BASELINE geometry: level-1 attention 1024 queries x 1800 keys, level-2 256 x 1032."""
+    _real_geometry_vs_oracle(G.UNET_1B, 128, 768, 1, 15, "1B 128x128 S=776 (largest key count)")
+
+
 def test_large_grid_properties(built_lib):
     """BASELINE config 5 geometry (128x128 tokens) on a narrow model: finite, deterministic, batch rows independent."""
     cfg = dict(G.UNET_MID)

@@ -19,13 +19,16 @@ ap.add_argument("--batch", type=int, default=1)
 ap.add_argument("--grid", type=int, default=32)
 ap.add_argument("--sample-steps", type=int, default=8)
 ap.add_argument("--gemm", default="fp32", choices=["fp32", "bf16"], help="bf16 = the opt-in fast mode of both models")
+ap.add_argument("--model", default="570m", choices=sorted(bench.MODELS))
+ap.add_argument("--s-byt5", type=int, default=0)
+ap.add_argument("--clip-image", type=int, default=0)
 ap.add_argument("--hook", action="append", default=[], metavar="NAME=INT", help="A/B: paella_test_NAME(INT) before the run")
 a = ap.parse_args()
 lib = _lib.load()
 for hk in a.hook:
     _lib.check(getattr(lib, "paella_test_" + hk.split("=")[0])(int(hk.split("=")[1])))
 dev = torch.device("cuda")
-mcfg, vcfg = bench.MODELS["570m"], bench.VQ["570m"]
+mcfg, vcfg = bench.MODELS[a.model], bench.VQ[a.model]
 model = paella_amd.Paella(**mcfg)
 synth.randomize_(model, seed=0)
 model = model.to(dev)
@@ -34,7 +37,7 @@ synth.randomize_(vq, seed=0)
 vq = vq.to(dev)
 model.set_gemm_precision(a.gemm)
 vq.set_gemm_precision(a.gemm)
-mk = lambda n, seed: synth.synth_conditioning(n, 0, mcfg["byt5_embd"], mcfg["clip_embd"], seed=seed, device=dev)
+mk = lambda n, seed: synth.synth_conditioning(n, a.s_byt5, mcfg["byt5_embd"], mcfg["clip_embd"], seed=seed, n_clip_image=a.clip_image, device=dev)
 c, u = mk(a.batch, 2), mk(a.batch, 3)
 kw = dict(steps=a.sample_steps, renoise_steps=a.sample_steps - 1, temperature=(1.0, 0.2), cfg=8.0, device=dev, noise="philox")
 
@@ -60,7 +63,8 @@ groups = collections.OrderedDict()
 for t, s in zip(us[:n], shp):
     groups.setdefault(tuple(int(v) for v in s), []).append(float(t))
 names = {0: "plain", 1: "GRN", 2: "LN", 3: "conv", 4: "GRNraw"}
-print("# python tools/gemm_by_shape.py --gemm %s %s --batch %d --grid %d --sample-steps %d: %d GEMM launches per image batch, event-timed, eager; per (M, N, K, prologue)" % (a.gemm, " ".join("--hook " + h for h in a.hook), a.batch, a.grid, a.sample_steps, n))
+print("# python tools/gemm_by_shape.py --gemm %s %s --model %s --s-byt5 %d --clip-image %d --batch %d --grid %d --sample-steps %d: %d GEMM launches per image batch, event-timed, eager; per (M, N, K, prologue)"
+      % (a.gemm, " ".join("--hook " + h for h in a.hook), a.model, a.s_byt5, a.clip_image, a.batch, a.grid, a.sample_steps, n))
 print("%-8s %-7s %-7s %-6s %6s %9s %9s %9s %7s" % ("M", "N", "K", "pro", "calls", "avg us", "min us", "total ms", "TF/s"))
 tot = 0.0
 for (M, N, K, pro, tail), ts in sorted(groups.items(), key=lambda kv: -sum(kv[1])):

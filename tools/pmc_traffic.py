@@ -37,12 +37,15 @@ def main():
     fetch_dir, write_dir, out = sys.argv[1:4]
     # optional: batch grid sample_steps of the profiled bench.py command (default: the headline workload)
     batch, grid, sample_steps = (int(v) for v in sys.argv[4:7]) if len(sys.argv) >= 7 else (1, 32, 8)
-    extra = "" if (batch, grid, sample_steps) == (1, 32, 8) else " --batch %d --grid %d --sample-steps %d" % (batch, grid, sample_steps)
+    # optional: the model name and the remaining bench.py flags of the profiled command (the 1B shares: "1b" "--s-byt5 256 --clip-image 1 [--inpaint]")
+    model = sys.argv[7] if len(sys.argv) >= 8 else "570m"
+    more = sys.argv[8] if len(sys.argv) >= 9 else ""
+    extra = "" if (model, batch, grid, sample_steps) == ("570m", 1, 32, 8) else " --model %s --batch %d --grid %d --sample-steps %d %s" % (model, batch, grid, sample_steps, more)
     f_kb, n_f = counter_avg(fetch_dir, "FETCH_SIZE", "gemm_nt_kernel")
     w_kb, n_w = counter_avg(write_dir, "WRITE_SIZE", "gemm_nt_kernel")
     hbm = (2.0 * f_kb + w_kb) * 1024.0
     j = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and a separate pass --pmc WRITE_SIZE) -- python bench.py%s --steps N --warmup 1 --no-cpu-baseline --no-extra --no-graph" % extra,
-         "workload": {"model": "570m", "batch_per_gpu": batch, "grid": grid, "sample_steps": sample_steps},
+         "workload": {"model": model, "batch_per_gpu": batch, "grid": grid, "sample_steps": sample_steps},
          "source_stamp": bench.source_stamp(), "stamped_sources": bench.TRAFFIC_SOURCES,
          "kernel": "gemm_nt_kernel (all instantiations)", "launches_profiled": n_f,
          "fetch_size_kb_avg_per_launch": round(f_kb, 2), "write_size_kb_avg_per_launch": round(w_kb, 2),
