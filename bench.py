@@ -99,6 +99,8 @@ def parse():
     ap.add_argument("--s-byt5", type=int, default=0, help="ByT5 conditioning rows (0 = CLIP-text only, the headline; 256 for the configs[3] / configs[4] shares)")
     ap.add_argument("--clip-image", type=int, default=0, help="number of CLIP image embeddings in the conditioning (configs[3] / configs[4]: 1)")
     ap.add_argument("--inpaint", action="store_true", help="the configs[4] path: VQGAN encode -> masked renoise -> sample(init_x, t_start 0.5) -> decode (eager)")
+    ap.add_argument("--no-roofline", action="store_true", help="profiling runs only (tools/collect_profiles.sh): skip rank 0's event-bracketed roofline pass -- the profiler then sees "
+                                                               "the timed steps alone; the line's `roofline` is null")
     ap.add_argument("--force-dist", action="store_true", help="take the torch.distributed (RCCL) path even at world size 1 (launch under torchrun)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="TEST ONLY: gloo moves device tensors through the host, which lets N ranks share one GPU")
     ap.add_argument("--share-device", action="store_true", help="TEST ONLY: every rank uses cuda:0 (needs --dist-backend gloo; RCCL refuses two ranks on one device)")
@@ -438,7 +440,7 @@ def run_workload(ctx, spec, steps, warmup, seed_base, fatal, with_latency_model=
             res["rehearsal"] = {"tokens_equal_unsharded": bool(torch.equal(toks, ft)), "images_equal_unsharded": bool(torch.equal(img, fi)),
                                 "tokens": int(toks.numel()), "row_offsets": [r * batch * grid * grid for r in range(world)]}
 
-    if rank == 0:  # the roofline pass (eager launches, every GEMM bracketed by events) runs on rank 0 alone; the others wait at the barrier below
+    if rank == 0 and not a.no_roofline:  # the roofline pass (eager launches, every GEMM bracketed by events) runs on rank 0 alone; the others wait at the barrier below
         c0, u0 = (cond_all, uncond_all) if not distributed else (shard_inputs(cond_all, lo, hi), shard_inputs(uncond_all, lo, hi))
         res["roofline"] = gemm_roofline(ctx.lib, lambda: run.eager(c0, u0, seed_base + 7), device, name, batch, grid, sample_steps, a.gemm, True,
                                         with_latency_model=with_latency_model)
@@ -565,7 +567,7 @@ def main():
         # / 8-step throughput entries of THIS run
         best = None
         if a.model == "570m" and (a.grid, a.sample_steps) == (32, 8):
-            cands = [{"batch_per_gpu": a.batch, "images_per_sec": round(value, 3), "ms_per_image": round(ms_per_step / total, 3), "executed_frac": head["roofline"]["executed_frac"]}]
+            cands = [{"batch_per_gpu": a.batch, "images_per_sec": round(value, 3), "ms_per_image": round(ms_per_step / total, 3), "executed_frac": (head.get("roofline") or {}).get("executed_frac")}]
             for t in throughput or []:
                 if "error" not in t and (t["model"], t["grid"], t["sample_steps"]) == ("570m", 32, 8):
                     cands.append({"batch_per_gpu": t["batch"], "images_per_sec": t["images_per_sec"], "ms_per_image": t["ms_per_image"], "executed_frac": t["roofline"]["executed_frac"]})
@@ -591,7 +593,7 @@ def main():
                        # step, min / max over ranks), event-timed conditioning broadcast + shard slicing, event-timed sampler (graph replay or eager launches) on rank 0
                        "per_rank_ms": head["per_rank_ms"], "broadcast_ms": head["broadcast_ms"], "broadcast_mbytes": round(head["broadcast_bytes"] / 1e6, 3),
                        "graph_replay_ms": head["sampler_ms"]},
-            "roofline": head["roofline"], "cpu_baseline": cpu, "best_256px_8step": best, "throughput": throughput, "fast_mode": fast_mode,
+            "roofline": head.get("roofline"), "cpu_baseline": cpu, "best_256px_8step": best, "throughput": throughput, "fast_mode": fast_mode,
         }
         if a.rehearsal:
             line["rehearsal"] = dict(head.get("rehearsal", {}), note="TEST ONLY (--rehearsal): tiny model, small sizes -- exercises the N > 1 code paths, not a measurement")

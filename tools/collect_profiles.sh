@@ -88,7 +88,7 @@ python tools/gemm_by_shape.py --gemm bf16 --batch 64 --grid 64 --sample-steps 2 
 { echo "# python -m pytest tests -m gpu -q -s -k 'parity or vs_oracle or vs_reference or closed_loop or benchmarked or geometry or train_step or prompts_to_image or graph_sampler or reproduces or grn_finished or nonsquare or largest_key or fused_attention or graph_inpainter'   (MI355X)"
   python -m pytest tests -m gpu -q -s -p no:cacheprovider -k "parity or vs_oracle or vs_reference or closed_loop or benchmarked or geometry or train_step or prompts_to_image or graph_sampler or reproduces or grn_finished or nonsquare or largest_key or fused_attention or graph_inpainter" 2>&1 | grep -v "amdgpu.ids" | grep -v "^\s*$"; } > $O/${TAG}_parity_report.txt
 { echo "# python -m pytest tests/test_gpu_fastmode.py tests/test_gpu_unet.py -q -s -k 'forward_deviation or sampling_fused or vqgan or layernorm_guard'   (MI355X): bf16 fast mode deviation / flip rates; LayerNorm guard inside the network"
-  python -m pytest tests/test_gpu_fastmode.py tests/test_gpu_unet.py -q -s -p no:cacheprovider -k "forward_deviation or sampling_fused or vqgan or layernorm_guard" 2>&1 | grep "fast mode\|guard in the network\|sampled tokens\|passed\|failed" | sed 's/^[.F]*//'; } > $O/${TAG}_fastmode_and_ln_guard_report.txt
+  python -m pytest tests/test_gpu_fastmode.py tests/test_gpu_unet.py -q -s -p no:cacheprovider -k "forward_deviation or sampling_fused or vqgan or layernorm_guard" 2>&1 | grep "fast mode\|guard in the network\|LayerNorm-folding\|sampled tokens\|passed\|failed" | sed 's/^[.F]*//'; } > $O/${TAG}_fastmode_and_ln_guard_report.txt
 # round 4: the LayerNorm-fold error curve (threshold hook at inf / 0 / default), the RCCL path at the box's world size
 { echo "# python -m pytest tests/test_gpu_ops.py -q -s -k layernorm_fold   (MI355X): max |out - fp64| of a LayerNorm-consuming GEMM, K = 1280, outputs of unit scale, per |row mean| / std"
   python -m pytest tests/test_gpu_ops.py -q -s -p no:cacheprovider -k "layernorm_fold" 2>&1 | grep "cfg\|passed\|failed" | sed 's/^[.F]*//'; } > $O/${TAG}_ln_fold_error_curve.txt
