@@ -131,3 +131,31 @@ def test_gemm_precision_is_a_per_model_switch_with_no_process_wide_state():
     assert not hasattr(paella_amd, "set_gemm_precision")
     assert not any("gemm_precision" in n for n in list(_lib.SIGNATURES) + list(_lib.TEST_HOOKS))
     assert "paella_unet_set_precision" in _lib.SIGNATURES and "paella_vqgan_set_precision" in _lib.SIGNATURES
+
+
+def test_bench_workload_tables_and_broadcast_layouts():
+    """bench.py's N > 1 path: the distributed table names BASELINE's two 8-GPU configurations at their per-GPU share (batch 256 / 8 = 32 and 128 / 8 = 16,
+    the second one the inpainting path), every workload has its SURVEY 8(d) algorithmic FLOPs, and the broadcast layout every rank derives from the request SHAPES alone
+    (cond_spec_layout) equals the layout of the tensors rank 0 actually packs (conditioning_layout) -- a mismatch would poison every step's broadcast."""
+    import bench
+    from paella_amd.dist import cond_spec_layout, conditioning_layout
+    dist_tab = [bench.EXTRA_WORKLOADS[i] for i in bench.EXTRA_DISTRIBUTED]
+    assert ("1b", 256 // 8, 64, 12, 256, 1, False) in [w[:7] for w in dist_tab]
+    assert ("1b", 128 // 8, 128, 12, 256, 1, True) in [w[:7] for w in dist_tab]
+    assert all(w[9] for w in bench.EXTRA_WORKLOADS), "every throughput workload goes through a captured graph"
+    assert all(w[7] >= 2 for w in bench.EXTRA_WORKLOADS), ">= 2 timed steps per workload"
+    for (name, batch, grid, steps, s_byt5, n_ci, inpaint, k, w, gr) in bench.EXTRA_WORKLOADS + bench.REHEARSAL_WORKLOADS:
+        if name != "tiny":
+            assert (name, grid, steps) in bench.ALGO_GFLOP_PER_IMAGE
+        cfg = bench.MODELS[name]
+        m = paella_amd.Paella(**cfg) if name == "tiny" else None
+
+        class _Shape:  # cond_spec_layout needs the embedding widths only
+            _cfg = cfg
+        for world in (1, 2, 8):
+            total = batch * world
+            mk = lambda seed: synth.synth_conditioning(min(total, 4), s_byt5, cfg["byt5_embd"], cfg["clip_embd"], seed=seed, n_clip_image=n_ci)
+            lay = cond_spec_layout(_Shape, min(total, 4), S_byt5=s_byt5, clip=True, n_clip_image=n_ci)
+            ref = conditioning_layout([mk(2), mk(3)])
+            assert lay[1] == ref[1] and [list(map(tuple, d)) for d in lay[0]] == [list(map(tuple, d)) for d in ref[0]]
+        del m
