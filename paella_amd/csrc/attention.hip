@@ -653,12 +653,16 @@ int launch_attention(const AttnArgs& a, hipStream_t st) {
     }
     // small query counts (batch-1 sampling grids) are latency chains -> split keys over waves; large ones re-read K/V
     // once per workgroup, so give a workgroup 64 queries instead
-    const bool ksplit = a.Lq < 256;
+    // (the key split buys CUs and cuts the latency chain 4x when the grid is small; once the 64-query form fills the chip by itself -- >= 1024 workgroups: batch >= 32 with
+    // guidance at the 64-position level -- it wins: no cross-wave merge, balanced key tiles.  variant 20 / 21 / 22 force the key-split / the LDS-staged / the register-fed 64-query form at 64..255 queries, A/B)
     const int variant = g_attn_variant.load();
+    const long wg64 = (long)((a.Lq + 63) / 64) * a.nhead * a.B;
+    const bool big = a.Lq >= 64 && (variant == 21 || variant == 22 || (variant != 20 && wg64 >= 1024));  // (22: the register-fed 64-query kernel instead of the LDS-staged one)
+    const bool ksplit = a.Lq < 256 && !big;
     // the direct-to-LDS stagings address K / V with 32-bit byte offsets behind a buffer descriptor whose num_records is clamped to 2 GiB: a per-sample K / V
     // span beyond that would be range-checked to zeros silently -- such a call takes the register-fed kernel, which uses 64-bit pointers
     const bool span32 = (size_t)a.Lself * (size_t)a.ld_self * 4 < ((size_t)1 << 31) && (size_t)a.Lcond * (size_t)a.ld_cond * 4 < ((size_t)1 << 31);
-    const bool lds = !ksplit && variant != 1 && span32;
+    const bool lds = !ksplit && variant != 1 && variant != 22 && span32;
     dim3 grid(ksplit ? (a.Lq + 15) / 16 : (a.Lq + 63) / 64, a.nhead, a.B);
 #define ATT_CASE(n)                                                                                                     \
     case n:                                                                                                             \

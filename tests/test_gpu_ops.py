@@ -339,7 +339,9 @@ def test_grn_scale(lib):
 
 @pytest.mark.parametrize("B,nh,D,Lq,Ls,Lc,nkw", [(2, 4, 16, 16, 16, 9, 0), (1, 16, 80, 64, 64, 4, 0), (2, 16, 80, 16, 16, 4, 3),
                                                  (1, 2, 32, 50, 0, 7, 0), (1, 4, 80, 100, 100, 37, 5), (2, 1, 128, 1, 1, 1, 0),
-                                                 (1, 2, 80, 300, 300, 21, 4), (1, 1, 16, 1030, 0, 520, 0)])
+                                                 (1, 2, 80, 300, 300, 21, 4), (1, 1, 16, 1030, 0, 520, 0),
+                                                 # 64..255 queries with >= 1024 64-query workgroups (batch >= 32 with guidance): the LDS-staged 64-query kernel instead of the key split
+                                                 (64, 16, 80, 64, 64, 4, 0), (40, 16, 80, 100, 100, 7, 3), (128, 8, 32, 72, 0, 9, 2)])
 def test_attention(lib, B, nh, D, Lq, Ls, Lc, nkw):
     g = torch.Generator().manual_seed(Lq * 3 + Lc)
     C = nh * D
