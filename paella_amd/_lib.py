@@ -103,6 +103,7 @@ TEST_HOOKS = {
     "paella_test_attention_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "paella_test_launch_chain": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     "paella_test_attention_variant": (c_int, [c_int]),
+    "paella_test_dwconv_strip": (c_int, [c_int]),
     "paella_test_gemm_dma": (c_int, [c_int]),
     "paella_test_gemm_raster": (c_int, [c_int]),
     "paella_test_gemm_ring": (c_int, [c_int]),

@@ -36,10 +36,17 @@
 #include <atomic>
 #include <mutex>
 #include <type_traits>
+#include <utility>
 #include <vector>
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): an "unrolled loop" that does not depend on the unroller's size budget
+template <typename F, int... Is>
+__device__ __forceinline__ void static_for_impl(F& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 struct SkPlan {
     int tiles_m, tiles_n;  // tile grid
@@ -171,8 +178,11 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? ring_wg_per_cu(WM, WN, TM,
     // (l % 8) ^ (row % 8)).  Needs K % BK == 0 (no activation-side K-tail mask) -- the host picks the register-staged twin otherwise.
     constexpr bool DMA_W = DMA || RING > 0, DMA_A = (DMA && (APRO == 0 || APRO == 2)) || RING > 0;  // (the LayerNorm is folded into the epilogue: the operand stays raw)
     static_assert(!DMA || (PD == 1 && BK == 32 && (BM * SL) % NT == 0 && (BN * SL) % NT == 0), "DMA variant: 1-deep, K step 32, whole passes");
-    static_assert(RING == 0 || (RING >= 3 && RING <= 4 && !DMA && PD == 1 && BK == 32 && !TAIL && APRO != 3 && (NW == 4 || (TM == 4 && TN == 4 && RING == 3)) && (BM * SL) % NT == 0 && (BN * SL) % NT == 0),
-                  "ring variant: 3 or 4 LDS stages, 4 waves (or 8 waves of 64x64 wave tiles), K step 32, whole passes, no implicit convolution");
+    // PP (RING == 2, bf16 operands only; tile id 37: 256x256): the "ping-pong" throughput tile of the fast mode -- see the PP block in the unit stream below
+    constexpr bool PP = RING == 2;
+    static_assert(!PP || (BF && NW == 8 && WM == 2 && WN == 4 && TM == 8 && TN == 4 && (APRO == 0 || APRO == 2)), "ping-pong tile: bf16 operands, 2 x 4 waves of 128x64 wave tiles");
+    static_assert(RING == 0 || (RING >= 2 && RING <= 4 && !DMA && PD == 1 && BK == 32 && !TAIL && APRO != 3 && (NW == 4 || (TM == 4 && TN == 4 && RING == 3) || PP) && (BM * SL) % NT == 0 && (BN * SL) % NT == 0),
+                  "ring variant: 3 or 4 LDS stages (2 for the ping-pong tile), 4 waves (or 8 waves of 64x64 / 128x64 wave tiles), K step 32, whole passes, no implicit convolution");
     static_assert(APRO != 4 || RING > 0, "the GRN-from-raw-statistics prologue exists on ring tiles only");
     constexpr bool BIG = RING > 0 && NW == 8;
     static_assert(!BIG || APRO != 4, "the 8-wave ring tile has no GRN-from-raw-statistics prologue");
@@ -325,11 +335,7 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? ring_wg_per_cu(WM, WN, TM,
     // and the epilogue skips the fold per ROW (ln_pre, per lane); without it (batch-1 launches on the 4-wave tiles) flagged 16-row blocks re-read the fp32 rows in
     // ln_fix.  The 8-wave bf16 tiles have no in-kernel fix (it spills there): the launcher always gives them the pre-pass.
     constexpr bool BF_FIX = BF && APRO == 2 && NW == 4;
-    bool ln_pre[(APRO == 2 && BF) ? TM : 1];
-    auto ln_pre_row = [&](int i) __attribute__((always_inline)) -> bool {
-        if constexpr (APRO == 2 && BF) return ln_pre[i];
-        else return false;
-    };
+    // (a pre-normalised row carries (mu, rstd) = (0, 1) from ln_row_stats on: rstd * (acc - 0 * wsum) is acc, bit for bit -- no per-lane flag array across the epilogue)
     bool ln_any = false;
     int ln_row0 = 0;  // first row of the (only) tile row this launch's LayerNorm statistics belong to
     const int ln_tile0 = ltile;
@@ -340,7 +346,12 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? ring_wg_per_cu(WM, WN, TM,
             int ln_tm, ln_tn;
             sk_tile_coords<(BM >= 64)>(p, ln_tile0, ln_tm, ln_tn);
             ln_row0 = ln_tm * BM;
-            if (g.ln_row) {  // finished once per row by launch_ln_rowstat_finalize (throughput regime): one 16-byte load per fragment row
+            // (the 8-wave bf16 tiles call this BEHIND their main loop: the lane id is re-derived from the hardware there -- a value carried across a main loop that
+            // uses every register is spilled -- and laundered, so that no row address is hoisted above the loop either)
+            int lane_l = (NW == 8 && BF) ? (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) : lane_k;
+            asm volatile("" : "+v"(lane_l));
+            const int r16 = lane_l & 15;
+            if (PP || g.ln_row) {  // finished once per row by launch_ln_rowstat_finalize (throughput regime; ALWAYS on the 8-wave bf16 tiles -- the ping-pong tile does not even carry the other path): one 16-byte load per fragment row
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     const int gmc = min(ln_tm * BM + (wm * TM + i) * 16 + r16, g.M - 1);
@@ -348,14 +359,15 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? ring_wg_per_cu(WM, WN, TM,
                     fr_mu[i] = v[0]; fr_rs[i] = v[1]; fr_mu_lo[i] = v[2];
                     if constexpr (BF) {
                         ln_dir[i] = false;
-                        ln_pre[i] = g.A != nullptr && v[3] > g.ln_fold_ratio;  // this lane's row was normalised by the pre-pass: no fold for it
-                        ln_any = ln_any || __builtin_amdgcn_ballot_w64(ln_pre[i]) != 0;  // (test counter only)
+                        const bool pre = g.A != nullptr && v[3] > g.ln_fold_ratio;  // this lane's row was normalised by the pre-pass: no fold for it
+                        if (pre) { fr_mu[i] = 0.f; fr_rs[i] = 1.f; }
+                        if (g.ln_guard_count) ln_any = ln_any || __builtin_amdgcn_ballot_w64(pre) != 0;  // (test counter only)
                     } else {
                         ln_dir[i] = __builtin_amdgcn_ballot_w64(v[3] > g.ln_fold_ratio) != 0;
                         ln_any = ln_any || ln_dir[i];
                     }
                 }
-                if (g.ln_guard_count && ln_any && lane_k == 0) atomicAdd(g.ln_guard_count, 1u);  // test hook only (null in the product)
+                if (g.ln_guard_count && ln_any && lane_l == 0) atomicAdd(g.ln_guard_count, 1u);  // test hook only (null in the product)
                 return;
             }
             const int nch = g.ln_nblk >> 1;
@@ -386,7 +398,6 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? ring_wg_per_cu(WM, WN, TM,
                 acc.finish(g.K, g.ln_eps, fr_mu[i], fr_rs[i]);
                 fr_mu_lo[i] = (float)(acc.S / (double)g.K - (double)fr_mu[i]);
                 ln_dir[i] = (!BF || (BF_FIX && g.A != nullptr)) && __builtin_amdgcn_ballot_w64(fabsf(fr_mu[i]) * fr_rs[i] > g.ln_fold_ratio) != 0;  // wave-uniform, a function of the block's 16 rows only
-                if constexpr (BF) ln_pre[i] = false;
                 ln_any = ln_any || ln_dir[i];
             }
             if (g.ln_guard_count && ln_any && lane_k == 0) atomicAdd(g.ln_guard_count, 1u);  // test hook only (null in the product)
@@ -707,8 +718,14 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? ring_wg_per_cu(WM, WN, TM,
         }
         f32x4 qq[GRN_FIN ? TM : 1][GRN_FIN ? TN : 1];  // ring tiles: per 16-row block, column sums of squares (GRN finished in the epilogue)
         const bool grn_fin = GRN_FIN && g.ep.grn_gx_out != nullptr;  // kernel-uniform
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
+        // one 16-row block of the wave tile.  `it` is the loop variable of a fully unrolled loop -- or, on the 32-block wave tile (256x256), an integral constant: a
+        // loop body of that size exceeds the compiler's budget for "#pragma unroll", the accumulators would be indexed at run time and live in scratch.
+        // (Measured and NOT kept, round 6: fetching the epilogue's operands ahead of its stores -- column operands once per tile, row operands per 16-row block.  gfx950
+        // counts vector loads and stores in ONE counter whose two classes complete out of order, so a load behind a store can only be waited for with vmcnt(0); but
+        // four workgroups per CU hide that round trip, and the restructured epilogue measured 0.5-1.4 % SLOWER per image in fp32 and no faster on the one-workgroup-per-CU
+        // bf16 tiles: profiles/r06_epilogue_operands_ahead_ab.txt.)
+        auto ep_row = [&](auto it) __attribute__((always_inline)) {
+            const int i = it;
             const int m = m0 + (wm * TM + i) * 16 + r16;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
@@ -718,7 +735,7 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? ring_wg_per_cu(WM, WN, TM,
                 if (ok) {
                     f32x4 a = acc[i][j];
                     if constexpr (APRO == 2) {
-                        if (!(ln_dir[i] || ln_pre_row(i))) a = (a - *reinterpret_cast<const f32x4*>(g.ln_wsum + nn) * fr_mu[i]) * fr_rs[i];  // the folded LayerNorm (see ln_row_stats)
+                        if (!ln_dir[i]) a = (a - *reinterpret_cast<const f32x4*>(g.ln_wsum + nn) * fr_mu[i]) * fr_rs[i];  // the folded LayerNorm (see ln_row_stats)
                     }
                     v = epilogue_apply<BF>(g.ep, g.N, m, nn, a);
                     epilogue_write(g.ep, g.C, g.ldc, m, nn, v);
@@ -746,6 +763,12 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? ring_wg_per_cu(WM, WN, TM,
                     }
                 }
             }
+        };
+        if constexpr (TM * TN >= 32) {
+            static_for<TM>(ep_row);
+        } else {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) ep_row(i);
         }
         if constexpr (GRN_FIN) {
             if (grn_fin) {
@@ -814,7 +837,7 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? ring_wg_per_cu(WM, WN, TM,
         sk_tile_coords<(BM >= 64)>(p, tile, tile_m, tile_n);
         // launder the lane id: everything the flush derives from it (fragment offsets, output rows / columns, masks) would
         // otherwise be hoisted out of the unit loop and held in ~80 VGPRs across the MFMA stream
-        int lane = lane_k;
+        int lane = PP ? (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) : lane_k;  // (the ping-pong tile's main loop leaves no register to carry it)
         asm volatile("" : "+v"(lane));
         const int r16 = lane & 15, kq = lane >> 4;
         if (DUAL) { acc[0][0] += acc2; acc2 = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -1003,14 +1026,161 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? ring_wg_per_cu(WM, WN, TM,
         };
         constexpr int PER_UNIT = LA + LB;  // LDS-DMA instructions per unit and wave; the last wave issues 2 (APRO 1) / 3 (APRO 4) more with the GRN side stage
         constexpr int SIDE_DMAS = (APRO == 4 || BIG) ? 3 : 2;
+        if constexpr (PP) {
+            // ===== 256x256 "ping-pong" tile (tile id 37; bf16 operands): 2 x 4 waves of 128x64 wave tiles, one workgroup per CU, two 64 KiB LDS buffers =====
+            // At bf16 MFMA rates (a 16x16x32 MFMA issues in ~17 cycles) the 256x128 tile's K step -- 6 LDS-DMA pieces (60-185 issue cycles each) and 16 fragment
+            // reads per wave against 32 MFMAs -- is bound by everything BUT the matrix cores (0.29 busy: profiles/r05_pmc_mfma_busy_bf16_fastmode_config3.txt).
+            // This tile halves both per MFMA (128x64 wave tiles: 24 reads and 8 pieces per 64 MFMAs) and hides them behind the OTHER wave of the SIMD, after
+            // the MI355X guide's 8-phase template (cdna_hip_programming.md, "The 256^2 8-phase template"):
+            //  * a K step (64 bf16) is four PHASES of 16 MFMAs = one quadrant (4 x 2 blocks) of the wave tile x both k groups:
+            //        P1 reads A rows 0..63 (8 reads) + W rows 0..31 (4) | P2 reads W rows 32..63 (4) | P3 reads A rows 64..127 (8) | P4 reads nothing (W rows 0..31 kept)
+            //  * a phase = [fragment reads, 2 LDS-DMA pieces] barrier [lgkmcnt(0), 16 MFMAs at raised priority] barrier; the wm = 1 waves run ONE barrier behind the
+            //    wm = 0 waves (waves w and w + 4 share a SIMD), so one group's MFMA block covers the other group's reads and DMA issue;
+            //  * the operand stream is cut into SECTIONS of two pieces per wave, issued one per phase, six sections ahead of their first use:
+            //        [A rows 0..63 | 128..191] [W rows 0..127] [W rows 128..255] [A rows 64..127 | 192..255]      (what P1 of each group needs comes first)
+            //    Section q = phase + 6 overwrites the buffer half whose last reads (two K steps earlier) were retired by an lgkmcnt(0) at least one barrier before -- for
+            //    BOTH groups (W halves: last read in P2, restaged from P4; A rows 0..63 / 128..191: P1, restaged from P3; the other A rows: P3, restaged from the next P2);
+            //  * counted waits only: vmcnt(6) in P4 (this wave's pieces of the next K step's first three sections have landed) and vmcnt(8) in P2 (the fourth section
+            //    of THIS K step, read from P3 on), each followed by both groups' barriers before the first read of those bytes.  Nothing waits for vmcnt(0) in the loop.
+            // Same k order per accumulator as every other bf16 tile (bit-identical results), same flush / epilogue / stream-K decomposition.
+            using I0 = std::integral_constant<int, 0>;
+            using I1 = std::integral_constant<int, 1>;
+            using I2 = std::integral_constant<int, 2>;
+            using I3 = std::integral_constant<int, 3>;
+            using I4 = std::integral_constant<int, 4>;
+            int lbuf = 0;  // LDS buffer of the load cursor's K step
+            auto pp_issue = [&](auto sec_tag) __attribute__((always_inline)) {
+                constexpr int sec = decltype(sec_tag)::value;
+                float* dAs = smem + lbuf * STAGE_FLOATS + (wave * (64 / SL)) * BK;  // this wave's 8 rows of every 64-row pass (wave-uniform -> M0)
+                float* dBs = dAs + BM * BK;
+                const int kofs = lkt * (BK * 4);
+                if constexpr (sec == 0) {
+                    dma_b128_to_lds(rsrcA, dAs, aoff[0], kofs);
+                    dma_b128_to_lds(rsrcA, dAs + 2 * RP * BK, aoff[2], kofs);
+                } else if constexpr (sec == 1) {
+                    dma_b128_to_lds(rsrcW, dBs, boff[0], kofs);
+                    dma_b128_to_lds(rsrcW, dBs + RP * BK, boff[1], kofs);
+                } else if constexpr (sec == 2) {
+                    dma_b128_to_lds(rsrcW, dBs + 2 * RP * BK, boff[2], kofs);
+                    dma_b128_to_lds(rsrcW, dBs + 3 * RP * BK, boff[3], kofs);
+                } else {
+                    dma_b128_to_lds(rsrcA, dAs + RP * BK, aoff[1], kofs);
+                    dma_b128_to_lds(rsrcA, dAs + 3 * RP * BK, aoff[3], kofs);
+                    lbuf ^= 1;
+                    if (++loaded < n) {  // the cursor stops on the range's last K step: re-issuing it keeps the piece count per phase constant (vmcnt arithmetic)
+                        if (++lkt == KT) {
+                            lkt = 0;
+                            ++ltile;
+                            set_tile(ltile);
+                        }
+                    }
+                }
+            };
+            f32x4 PA[2][4], PBl[2][2], PBh[2][2];  // fragments by k group: four A row blocks, the low / high pair of W row blocks
+            auto rdA = [&](int st, auto ib_tag) __attribute__((always_inline)) {
+                constexpr int ib = decltype(ib_tag)::value;
+                const float* As = smem + st * STAGE_FLOATS;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const int c4 = kk * 4 + kq;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int row = (wm * TM + ib + i) * 16 + r16;
+                        PA[kk][i] = *reinterpret_cast<const f32x4*>(As + row * BK + ((c4 ^ (row & (SL - 1))) << 2));
+                    }
+                }
+            };
+            auto rdB = [&](f32x4 (&dst)[2][2], int st, auto jb_tag) __attribute__((always_inline)) {
+                constexpr int jb = decltype(jb_tag)::value;
+                const float* Bs = smem + st * STAGE_FLOATS + BM * BK;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const int c4 = kk * 4 + kq;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int row = (wn * TN + jb + j) * 16 + r16;
+                        dst[kk][j] = *reinterpret_cast<const f32x4*>(Bs + row * BK + ((c4 ^ (row & (SL - 1))) << 2));
+                    }
+                }
+            };
+            auto mm = [&](auto ib_tag, auto jb_tag, const f32x4 (&pb)[2][2]) __attribute__((always_inline)) {
+                constexpr int ib = decltype(ib_tag)::value, jb = decltype(jb_tag)::value;
+                // the compute half of a phase: everything this wave read has arrived, then 16 MFMAs (k group outermost: two MFMAs on one accumulator are 8 apart)
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) acc[ib + i][jb + j] = mma_bf16(pb[kk][j], PA[kk][i], acc[ib + i][jb + j]);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            };
+            // prologue: the first K step whole + the first two sections of the second one
+            pp_issue(I0{}); pp_issue(I1{}); pp_issue(I2{}); pp_issue(I3{}); pp_issue(I0{}); pp_issue(I1{});
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // sections 0..2 of the first K step (this wave's pieces)
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            int cbuf = 0;
+            int ctile = (int)fast_div(u0, p.dKT);
+            int ckt = (int)(u0 - (unsigned)ctile * (unsigned)KT);
+            bool first_seg = true;
+            for (int i = 0; i < n;) {
+                const int seg_len = min(KT - ckt, n - i);
+                if (wm == 1) __builtin_amdgcn_s_barrier();  // the second wave group runs one barrier behind from here ...
+                asm volatile("" ::: "memory");
+                for (int s2 = 0; s2 < seg_len; ++s2) {
+                    // P1
+                    rdA(cbuf, I0{});
+                    rdB(PBl, cbuf, I0{});
+                    __builtin_amdgcn_sched_barrier(0);
+                    pp_issue(I2{});
+                    mm(I0{}, I0{}, PBl);
+                    // P2
+                    rdB(PBh, cbuf, I2{});
+                    __builtin_amdgcn_sched_barrier(0);
+                    pp_issue(I3{});
+                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // this K step's last section (A rows 64..127 / 192..255), read from P3 on
+                    mm(I0{}, I2{}, PBh);
+                    // P3
+                    rdA(cbuf, I4{});
+                    __builtin_amdgcn_sched_barrier(0);
+                    pp_issue(I0{});
+                    mm(I4{}, I2{}, PBh);
+                    // P4
+                    pp_issue(I1{});
+                    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // the next K step's first three sections, read from its P1 on
+                    mm(I4{}, I0{}, PBl);
+                    cbuf ^= 1;
+                }
+                if (wm == 0) __builtin_amdgcn_s_barrier();  // ... to here: both groups aligned again for the flush (its ticket hand-off needs every wave's stores behind ONE barrier)
+                asm volatile("" ::: "memory");
+                if (i + seg_len == n) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may still be landing when the workgroup's LDS is released
+                // LayerNorm row statistics (always the pre-pass form on this tile: one 16-byte load per fragment row) are fetched HERE, not ahead of the unit
+                // stream: 40 registers held across the main loop spill (608 bytes per lane); a LayerNorm-consuming range never leaves its tile row
+                if (first_seg) ln_row_stats();
+                flush(ctile, ckt, ckt + seg_len, first_seg);
+                first_seg = false;
+                i += seg_len;
+                ckt += seg_len;
+                if (ckt == KT) { ckt = 0; ++ctile; }
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < RING - 1; ++j) fetch_ring(j);
-        ln_row_stats();  // while the first units are in flight
+        if constexpr (!BIG) ln_row_stats();  // while the first units are in flight (the 8-wave tile: before its flush -- 16 more registers across its main loop spill)
         int cs = 0, ls = RING - 1;
         int ctile = (int)fast_div(u0, p.dKT);
         int ckt = (int)(u0 - (unsigned)ctile * (unsigned)KT);
         bool first_seg = true;
-        if constexpr (BIG) {
+        if constexpr (BIG && !PP) {
             // ===== 8 waves x (64x64 wave tile): fragments by 16-wide k group, read one group ahead of the MFMAs =====
             //   barrier(u) | DMA unit u+2 -> the stage unit u-1 left | read group 0 of unit u | MFMA group 1 of unit u-1 | read group 1 of unit u | MFMA group 0 of unit u
             // Every ds_read runs under 64 MFMAs that do not need it (the GRN scale / shift fragments ride with the operand fragments and are applied right
@@ -1098,6 +1268,7 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? ring_wg_per_cu(WM, WN, TM,
                 mfma_group(I1{}, I0{}, I4{});
                 __builtin_amdgcn_sched_barrier(0);
                 if (i + seg_len == n) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may still be landing when the workgroup's LDS is released
+                if (first_seg) ln_row_stats();  // (a LayerNorm-consuming range never leaves its tile row: once)
                 flush(ctile, ckt, ckt + seg_len, first_seg);
                 first_seg = false;
                 i += seg_len;
@@ -1276,6 +1447,8 @@ static const TileCfg kCfgs[] = {
     {2, 2, 1, 2, 1, 32, 4},  // 35: 32x64, 4 stages
     // the throughput-regime tile: 8 waves of 64x64 wave tiles, both operands by LDS-DMA into 3 stages, fragments read one k group ahead (BIG in the kernel)
     {4, 2, 4, 4, 1, 32, 3},  // 36: 256x128
+    // the bf16 fast mode's throughput tile: 2 x 4 waves of 128x64 wave tiles, two 64 KiB LDS buffers, phases of 16 MFMAs with the two wave groups one barrier apart (PP in the kernel)
+    {2, 4, 8, 4, 1, 32, 2},  // 37: 256x256 (bf16 operands only)
 };
 static const int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 int gemm_num_tile_configs() { return kNumCfgs; }
@@ -1355,8 +1528,8 @@ static void launch_bf(const GemmArgs& g, const SkPlan& p, unsigned G, float* sla
     else
         hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, 1, 0, false, 32, DMAv, RINGv, true>), dim3(G), dim3(NT), 0, st, g, p, slabs, tickets, slab_bytes);
 }
-// tile configs that carry a bf16 variant: the direct-to-LDS twins (10, 18, 19) and the ring tiles (30..36)
-static bool bf16_cfg(int cfg) { return cfg == 10 || cfg == 18 || cfg == 19 || (cfg >= 30 && cfg <= 36); }
+// tile configs that carry a bf16 variant: the direct-to-LDS twins (10, 18, 19), the ring tiles (30..36) and the ping-pong tile (37)
+static bool bf16_cfg(int cfg) { return cfg == 10 || cfg == 18 || cfg == 19 || (cfg >= 30 && cfg <= 37); }
 static bool launch_bf_cfg(int cfg, const GemmArgs& g, const SkPlan& p, unsigned G, float* slabs, unsigned* tickets, unsigned slab_bytes, hipStream_t st) {
     switch (cfg) {
         case 10: launch_bf<2, 4, 4, 2, true, 0>(g, p, G, slabs, tickets, slab_bytes, st); return true;
@@ -1369,6 +1542,7 @@ static bool launch_bf_cfg(int cfg, const GemmArgs& g, const SkPlan& p, unsigned 
         case 34: launch_bf<2, 2, 2, 2, false, 3>(g, p, G, slabs, tickets, slab_bytes, st); return true;
         case 35: launch_bf<2, 2, 1, 2, false, 4>(g, p, G, slabs, tickets, slab_bytes, st); return true;
         case 36: launch_bf<4, 2, 4, 4, false, 3>(g, p, G, slabs, tickets, slab_bytes, st); return true;
+        case 37: launch_bf<2, 4, 8, 4, false, 2>(g, p, G, slabs, tickets, slab_bytes, st); return true;
         default: return false;
     }
 }
@@ -1791,7 +1965,7 @@ static int launch_gemm_cfg_impl(const GemmArgs& g_in, int cfg, int splitk, void*
         const size_t row4_off = (ws_bytes - bytes) & ~(size_t)255;
         float* row4 = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + row4_off);
         slab_cap = row4_off - kGemmTicketBytes;
-        const int rc = launch_ln_rowstat_finalize(g.ln_stats, g.ln_nblk, g.K, g.ln_eps, row4, g.M, bf ? g.A : nullptr, bf ? const_cast<unsigned short*>(g.A16) : nullptr, g.lda,
+        const int rc = launch_ln_rowstat_finalize(g.ln_stats, g.ln_nblk, g.K, g.ln_eps, row4, g.M, bf ? g.A : nullptr, (bf && g.A) ? const_cast<unsigned short*>(g.A16) : nullptr, g.lda,
                                                   g_ln_fold_ratio.load(std::memory_order_relaxed), g_ln_guard_count.load(std::memory_order_relaxed), st);
         if (rc != PAELLA_OK) return rc;
         g.ln_row = row4;
@@ -1816,12 +1990,13 @@ static int launch_gemm_cfg_impl(const GemmArgs& g_in, int cfg, int splitk, void*
     }
     const TileCfg& tc = kCfgs[cfg];
     const int BM = tc.wm * tc.tm * 16, BN = tc.wn * tc.tn * 16;
-    if (bf && g.ln_stats && g.A && !g.ln_row && tc.wm * tc.wn == 8) {  // the 8-wave bf16 tiles have no in-kernel operand-side guard: the pre-pass it is, whatever M
+    // the 8-wave bf16 tiles have no in-kernel operand-side guard: the pre-pass it is, whatever M; the ping-pong tile carries ONLY the pre-pass form of the row statistics
+    if (bf && g.ln_stats && !g.ln_row && (tc.ring == 2 || (g.A && tc.wm * tc.wn == 8))) {
         if (!prepass_fits) { paella_set_error("gemm: a bf16 LayerNorm-consuming launch on an 8-wave tile needs a workspace (>= 80 MiB + 16 bytes per row) for the row pre-pass"); return PAELLA_ERR_WORKSPACE; }
         const int rc = ln_prepass();
         if (rc != PAELLA_OK) return rc;
     }
-    if (bf && !bf16_cfg(cfg)) { paella_set_error("gemm: tile config %d has no bf16-operand variant (10, 18, 19, 30..36 do)", cfg); return PAELLA_ERR_ARG; }
+    if (bf && !bf16_cfg(cfg)) { paella_set_error("gemm: tile config %d has no bf16-operand variant (10, 18, 19, 30..37 do)", cfg); return PAELLA_ERR_ARG; }
     if ((g.grn_gx || g.ep.grn_gx_out) && (!tc.ring || tc.wm * tc.wn == 8)) { paella_set_error("gemm: the in-epilogue / on-load GRN statistics need a ring tile (got tile %d)", cfg); return PAELLA_ERR_STATE; }
     if (g.grn_gx && (!g.grn_gamma || !g.a_shift || !g.grn_part || g.grn_np <= 0 || g.a_scale || g.ln_stats || g.a_rows_per_sample % 16)) {
         paella_set_error("gemm: bad GRN-from-statistics operand description"); return PAELLA_ERR_ARG;
@@ -1918,6 +2093,7 @@ static int launch_gemm_cfg_impl(const GemmArgs& g_in, int cfg, int splitk, void*
         case 34: launch_ring<2, 2, 3>(g, p, G, slabs, tickets, slab_bytes, st); break;
         case 35: launch_ring<1, 2, 4>(g, p, G, slabs, tickets, slab_bytes, st); break;
         case 36: paella_set_error("gemm: tile config 36 (256x128) exists for bf16 operands only (in fp32 it measured 4-6 %% behind the 64x64 tile: profiles/r04_gemm_big_tile_sweep.txt)"); return PAELLA_ERR_ARG;
+        case 37: paella_set_error("gemm: tile config 37 (256x256 ping-pong) exists for bf16 operands only"); return PAELLA_ERR_ARG;
         default: paella_set_error("gemm: bad tile config %d", cfg); return PAELLA_ERR_ARG;
     }
 #undef GEMM_CASE

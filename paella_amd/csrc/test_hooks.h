@@ -28,6 +28,9 @@ int paella_test_launch_chain(float* buf, int n_elems, int blocks, int n_launches
  * 11 = its padded direct-to-LDS layout at every head_dim; 0 = default = direct-to-LDS staging, unpadded (4 workgroups per CU) at odd head_dim / 16, padded otherwise
  * (attention.hip: STG; bit-identical outputs; A/B probe tools/attn_probe.py) */
 int paella_test_attention_variant(int v);
+/* depthwise 3x3 + LayerNorm: 0 = always one workgroup per position, 1 = default (strips of 8 positions per workgroup from 4096 positions up), 2 = strips whenever
+ * the strip kernel has an instantiation (<= 2048 channels, no skip input); bit-identical outputs (tests/test_gpu_ops.py) */
+int paella_test_dwconv_strip(int mode);
 /* C = prologue(A) . W^T with an explicit tile config / workgroup count (as paella_op_gemm): mode 1: a' = a * scale[row / rows_per_sample][k] +
  * shift[k] (the GRN apply of the MLP's second GEMM); mode 2: a' = (a - mean) * rstd from ln_stats [M, K/16, 2] = per 16-column block (sum, M2 =
  * sum of squared deviations from the block mean) (LayerNorm folded into the consumer's EPILOGUE; the hook sums W's rows itself with one extra M = 1 launch per call) */

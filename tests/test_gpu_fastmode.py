@@ -18,7 +18,7 @@ from tests.helpers import cond_for, to_dev, weights_for
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
-BF16_TILES = [10, 18, 19, 30, 31, 32, 33, 34, 35, 36]  # paella_amd/csrc/gemm.hip: bf16_cfg()
+BF16_TILES = [10, 18, 19, 30, 31, 32, 33, 34, 35, 36, 37]  # paella_amd/csrc/gemm.hip: bf16_cfg()
 
 
 def _p(t):
@@ -84,7 +84,7 @@ def test_bf16_gemm_epilogue_gelu_is_the_12_instruction_fit_within_its_stated_bou
     assert (C32.cpu().double() - F.gelu(x.double())).abs().max().item() < 2e-6
 
 
-@pytest.mark.parametrize("tile,splitk", [(10, 1), (18, 1), (18, 2), (19, 1), (30, 1), (30, 5), (31, 1), (31, 2), (34, 1), (36, 1), (36, 2), (-1, 1)])
+@pytest.mark.parametrize("tile,splitk", [(10, 1), (18, 1), (18, 2), (19, 1), (30, 1), (30, 5), (31, 1), (31, 2), (34, 1), (36, 1), (36, 2), (37, 1), (37, 2), (-1, 1)])
 def test_bf16_gemm_layernorm_fold(built_lib, tile, splitk):
     """LayerNorm folded into the epilogue of a bf16 GEMM: rstd * (sum_k a16 W16 - mean * sum_k W16) with (mean, rstd) from the fp32 rows' centred partials
     -- exactly the LayerNorm arithmetic applied to the ROUNDED operand with the fp32 row statistics."""
@@ -138,7 +138,7 @@ def test_bf16_gemm_stream_k_is_repeatable(built_lib):
     A, W, bias, _ = _operands(M, N, K, 5)
     A16, W16, bd = A.bfloat16().to(DEV), W.bfloat16().to(DEV), bias.to(DEV)
     ws = _lib.new_workspace(128 << 20, DEV)
-    for tile, Gw in [(30, 512), (30, 1280), (31, 777), (32, 300), (33, 301), (34, 100), (35, 64), (36, 7), (36, 40), (18, 100), (10, 33), (19, 640)]:
+    for tile, Gw in [(30, 512), (30, 1280), (31, 777), (32, 300), (33, 301), (34, 100), (35, 64), (36, 7), (36, 40), (37, 3), (37, 9), (18, 100), (10, 33), (19, 640)]:
         outs = []
         for it in range(6):
             C = torch.full((M, N), float("nan"), device=DEV)
@@ -281,7 +281,7 @@ def test_bf16_attention_core(built_lib, B, nh, D, Lq, Ls, Lc, nkw):
 # |row mean| / std = r the copy's rounding is r * 2^-9 of a standard deviation per element, which no epilogue arithmetic can undo.  16-row blocks above the
 # fold threshold therefore re-read the fp32 rows, normalise in fp32 and round the NORMALISED operand to bf16 (gemm.hip: ln_fix, BF form).
 # ---------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("tile,splitk", [(10, 1), (18, 1), (18, 2), (19, 1), (30, 1), (30, 5), (31, 1), (31, 2), (32, 1), (33, 1), (34, 1), (35, 1), (35, 3), (36, 1), (36, 2), (-1, 1)])
+@pytest.mark.parametrize("tile,splitk", [(10, 1), (18, 1), (18, 2), (19, 1), (30, 1), (30, 5), (31, 1), (31, 2), (32, 1), (33, 1), (34, 1), (35, 1), (35, 3), (36, 1), (36, 2), (37, 1), (37, 2), (-1, 1)])
 def test_bf16_gemm_layernorm_guard_every_tile(built_lib, tile, splitk):
     """Rows 0..79 have |mean| / std = 160 (five flagged 16-row blocks), the rest ~0.2 (fold).  Reference, in fp64: flagged blocks = bf16(LayerNorm(A)) . W16^T,
     the others = the fold on the rounded operand; every K position of every tile x work split must hit the right fp32 elements (asymmetric operands)."""

@@ -31,7 +31,7 @@ SHAPES = {
     "c3 L1 qkv 32768x3840x1280": (32768, 3840, 1280), "c3 L1 out 32768x1280x1280": (32768, 1280, 1280),
     "c3 L2 mlp1 8192x5120x1280": (8192, 5120, 1280), "c3 L2 mlp2 8192x1280x5120": (8192, 1280, 5120),
 }
-TILE = {10: (128, 128), 18: (64, 64), 19: (32, 32), 30: (32, 32), 31: (32, 32), 32: (32, 64), 33: (64, 32), 34: (64, 64), 35: (32, 64), 36: (256, 128)}
+TILE = {10: (128, 128), 18: (64, 64), 19: (32, 32), 30: (32, 32), 31: (32, 32), 32: (32, 64), 33: (64, 32), 34: (64, 64), 35: (32, 64), 36: (256, 128), 37: (256, 256)}
 
 
 def main():
@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--only", default=None, help="substring filter on the shape name (comma-separated alternatives)")
     ap.add_argument("--ln", action="store_true", help="LayerNorm folded into the epilogue (row statistics operand)")
     ap.add_argument("--act", type=int, default=0, help="1 = bias + GELU epilogue and a bf16-only output (the MLP's first GEMM)")
+    ap.add_argument("--no-store", action="store_true", help="no output at all (C and C16 null): main loop + ramp only -- what the epilogue's stores cost is the difference")
     a = ap.parse_args()
     lib = _lib.load()
     st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -52,7 +53,7 @@ def main():
         A = torch.randn(M, K, device="cuda").bfloat16()
         Ws = [(torch.randn(N, K, device="cuda") / K ** 0.5).bfloat16() for _ in range(ncopy)]
         bias = torch.randn(N, device="cuda") if a.act else None
-        C = torch.empty(M, N, device="cuda") if not a.act else None
+        C = torch.empty(M, N, device="cuda") if not (a.act or a.no_store) else None
         C16 = torch.empty(M, N, device="cuda", dtype=torch.bfloat16) if a.act else None
         stats = torch.stack([torch.zeros(M, K // 16, device="cuda"), torch.full((M, K // 16), 16.0, device="cuda")], dim=-1).contiguous() if a.ln else None
         big = M >= 4096
