@@ -99,11 +99,11 @@ TEST_HOOKS = {
     "paella_prof_collect": (c_int, [POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int64)]),
     "paella_test_gemm_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "paella_test_gemm_bf16_rule": (c_int, [c_int]),
+    "paella_test_grn_apply16": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "paella_test_gemm_bf16_ln": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "paella_test_attention_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "paella_test_launch_chain": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     "paella_test_attention_variant": (c_int, [c_int]),
-    "paella_test_dwconv_strip": (c_int, [c_int]),
     "paella_test_gemm_dma": (c_int, [c_int]),
     "paella_test_gemm_raster": (c_int, [c_int]),
     "paella_test_gemm_ring": (c_int, [c_int]),

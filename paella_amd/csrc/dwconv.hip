@@ -8,8 +8,6 @@
 // Skip variant = Conv2d(2C -> C, groups=C) over cat([x, skip]): output channel g reads concatenated channels 2g, 2g+1;
 // weights repacked [j][tap][C].
 #include "common.h"
-#include "test_hooks.h"
-#include <atomic>
 
 __device__ __forceinline__ f32x4 ldq(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
@@ -103,133 +101,6 @@ __global__ __launch_bounds__(256) void dwconv_ln_block_kernel(const float* __res
     }
 }
 
-// Throughput form (>= kStripMinPositions positions, no skip input): one workgroup per STRIP of P consecutive positions of one image row.
-// The block kernel above reads 9 neighbour rows per position -- 9x the activation bytes through the L2s, and with workgroups dealt round-robin over the
-// 8 XCDs the neighbours of a position sit in OTHER L2s (32768 positions x 1280 channels: 107 us = 2.3 TB/s of algorithmic bytes).  A strip reads
-// 3 x (P + 2) rows for P outputs (3.75x at P = 8) with all loads of an input row in flight together, strips are dealt to the XCDs in contiguous runs so the
-// image rows above / below a strip are in the same L2, and the P LayerNorm reductions share two barrier pairs.
-// BIT-IDENTICAL to the block kernel (tests/test_gpu_ops.py): per output the taps are accumulated in the same order (ky outer, kx inner) with the same
-// operations (acc += x * (w * keep)), channels map to threads the same way, and the block sums reduce in the same order.
-template <int NV, int P>
-__global__ __launch_bounds__(256) void dwconv_ln_strip_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                                                              float* __restrict__ y, unsigned short* __restrict__ y16, int H, int W, int C, float eps,
-                                                              unsigned nstrips, int strips_per_row, FastDiv dS, FastDiv dH) {
-    __shared__ float red[2][4][P];
-    unsigned sid = blockIdx.x;
-    {   // workgroup b runs on XCD b % 8: XCD x owns the contiguous strips [x*q + min(x, r), ...) (q + 1 of them when x < r)
-        const unsigned q = nstrips >> 3, r = nstrips & 7;
-        const unsigned xcd = sid & 7, idx = sid >> 3;
-        sid = xcd * q + min(xcd, r) + idx;
-    }
-    const unsigned prow = fast_div(sid, dS);  // b * H + y
-    const int x0 = (int)(sid - prow * (unsigned)strips_per_row) * P;
-    const int yy = (int)(prow - fast_div(prow, dH) * (unsigned)H);
-    const int64_t img = (int64_t)(prow - (unsigned)yy) * W;  // row index of (b, 0, 0)
-    const int C4 = C >> 2;
-    int c4s[NV];
-    bool live[NV];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c4 = threadIdx.x + i * 256;
-        live[i] = c4 < C4;
-        c4s[i] = live[i] ? c4 : C4 - 1;
-    }
-    f32x4 acc[P][NV];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const f32x4 b = ldq(bias + c4s[i] * 4);
-#pragma unroll
-        for (int p = 0; p < P; ++p) acc[p][i] = b;
-    }
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-        const int sy = yy + ky - 1;
-        const int syc = min(max(sy, 0), H - 1);
-        const float rowkeep = sy == syc ? 1.0f : 0.0f;
-        const float* xr = x + (img + (int64_t)syc * W) * C;
-        f32x4 wr[3][NV];
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-            for (int i = 0; i < NV; ++i) wr[kx][i] = ldq(w + (ky * 3 + kx) * C + c4s[i] * 4);
-        f32x4 v[P + 2][NV];  // every load of the input row is issued before the first use
-#pragma unroll
-        for (int c = 0; c < P + 2; ++c) {
-            const int sxc = min(max(x0 + c - 1, 0), W - 1);
-#pragma unroll
-            for (int i = 0; i < NV; ++i) v[c][i] = ldq(xr + (int64_t)sxc * C + c4s[i] * 4);
-        }
-#pragma unroll
-        for (int c = 0; c < P + 2; ++c) {
-            const int sx = x0 + c - 1;
-            const float keep = (sx >= 0 && sx < W) ? rowkeep : 0.0f;  // zero padding: a 0 / 1 factor on the tap, as in the block kernel
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int p = c - kx;  // input column c - 1 is tap kx of output p = (c - 1) + 1 - kx
-                if (p >= 0 && p < P) {
-#pragma unroll
-                    for (int i = 0; i < NV; ++i) acc[p][i] += v[c][i] * (wr[kx][i] * keep);
-                }
-            }
-        }
-    }
-    // LayerNorm of the P positions: two block reductions for all of them together, each in block_sum_256's order
-    const int wave = threadIdx.x >> 6;
-    float mean[P], rstd[P];
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-        float s = 0.f;
-#pragma unroll
-        for (int i = 0; i < NV; ++i)
-            if (live[i]) s += (acc[p][i][0] + acc[p][i][1]) + (acc[p][i][2] + acc[p][i][3]);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-        if ((threadIdx.x & 63) == 0) red[0][wave][p] = s;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int p = 0; p < P; ++p) mean[p] = ((red[0][0][p] + red[0][1][p]) + (red[0][2][p] + red[0][3][p])) / (float)C;
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-        float q = 0.f;
-#pragma unroll
-        for (int i = 0; i < NV; ++i)
-            if (live[i]) {
-                f32x4 d = acc[p][i] - mean[p];
-                d = d * d;
-                q += (d[0] + d[1]) + (d[2] + d[3]);
-            }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
-        if ((threadIdx.x & 63) == 0) red[1][wave][p] = q;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int p = 0; p < P; ++p) rstd[p] = 1.0f / sqrtf(((red[1][0][p] + red[1][1][p]) + (red[1][2][p] + red[1][3][p])) / (float)C + eps);
-    const int64_t pos0 = img + (int64_t)yy * W + x0;
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-        if (x0 + p >= W) break;
-        if (y16) {
-            typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-#pragma unroll
-            for (int i = 0; i < NV; ++i)
-                if (live[i]) *reinterpret_cast<bf16x4*>(y16 + (pos0 + p) * C + (threadIdx.x + i * 256) * 4) = __builtin_convertvector((acc[p][i] - mean[p]) * rstd[p], bf16x4);
-        }
-        if (y) {
-#pragma unroll
-            for (int i = 0; i < NV; ++i)
-                if (live[i]) *reinterpret_cast<f32x4*>(y + (pos0 + p) * C + (threadIdx.x + i * 256) * 4) = (acc[p][i] - mean[p]) * rstd[p];
-        }
-    }
-}
-
-// positions from which the strip kernel takes over (below: the latency-bound batch-1 launches keep one workgroup per position).  Test hook: 0 = never,
-// 1 = the rule (default), 2 = whenever the strip kernel has an instantiation (bit-identity test, A/B)
-static const int64_t kStripMinPositions = 4096;
-static std::atomic<int> g_dwconv_strip{1};
-extern "C" int paella_test_dwconv_strip(int mode) { g_dwconv_strip = mode; return PAELLA_OK; }
-
 int launch_dwconv_ln(const float* x, const float* skip, const float* w, const float* bias, float* y, int B, int H,
                      int W, int C, float eps, hipStream_t st, unsigned short* y16) {
     const int64_t total = (int64_t)B * H * W;
@@ -238,17 +109,6 @@ int launch_dwconv_ln(const float* x, const float* skip, const float* w, const fl
     if ((C & 3) || (skip && (C & 7)) || C > 8192 || (skip && C > 4096)) { paella_set_error("dwconv_ln: bad channel count %d", C); return PAELLA_ERR_ARG; }
     if (total > 0x7fffffff) { paella_set_error("dwconv_ln: too many positions"); return PAELLA_ERR_ARG; }
     const int nv = (C / 4 + 255) / 256;
-    const int strip_mode = g_dwconv_strip.load(std::memory_order_relaxed);
-    if (!skip && nv <= 2 && strip_mode != 0 && (strip_mode == 2 || total >= kStripMinPositions)) {
-        constexpr int P = 8;
-        const int spr = (W + P - 1) / P;
-        const unsigned nstrips = (unsigned)((int64_t)B * H * spr);
-        const FastDiv dS = fast_div_of((unsigned)spr), dHs = fast_div_of((unsigned)H);
-        if (nv <= 1) hipLaunchKernelGGL((dwconv_ln_strip_kernel<1, P>), dim3(nstrips), dim3(256), 0, st, x, w, bias, y, y16, H, W, C, eps, nstrips, spr, dS, dHs);
-        else hipLaunchKernelGGL((dwconv_ln_strip_kernel<2, P>), dim3(nstrips), dim3(256), 0, st, x, w, bias, y, y16, H, W, C, eps, nstrips, spr, dS, dHs);
-        LAUNCH_CHECK_RET();
-        return PAELLA_OK;
-    }
     const dim3 grid((unsigned)total), block(256);
     const FastDiv dW = fast_div_of((unsigned)W), dH = fast_div_of((unsigned)H);
 #define DW_LAUNCH(NVv)                                                                                                   \

@@ -1764,13 +1764,24 @@ extern "C" int paella_test_gemm_bf16_rule(int mask) { g_bf16_rule = mask; return
 static void choose_config_bf16(int M, int N, int K, int apro, size_t slab_cap_bytes, int* cfg_out, unsigned* G_out) {
     const long ktiles = K / 64;
     const double macs = (double)M * N * K;
-    const long T256 = tiles_of_cfg(36, M, N), T128 = tiles_of_cfg(10, M, N), T64 = tiles_of_cfg(18, M, N);
+    const long T256 = tiles_of_cfg(36, M, N), T128 = tiles_of_cfg(10, M, N), T64 = tiles_of_cfg(18, M, N), TPP = tiles_of_cfg(37, M, N);
     const int rule = g_bf16_rule.load(std::memory_order_relaxed);
-    const bool no_big = (rule & 1) != 0, no_persist = (rule & 2) != 0;
+    const bool no_big = (rule & 1) != 0, no_persist = (rule & 2) != 0, no_pp = (rule & 4) != 0;
     int cfg;
     long G;
     // (profiles/r05_gemm_bf16_tile_sweep.txt; TFLOP/s in isolation, fp32 outputs)
-    if (T256 >= 1024 && (K <= 768 || N < 512)) {
+    // share of the chip's tile slots a launch of T one-per-workgroup tiles keeps busy over its ceil(T / 256) rounds
+    auto round_eff = [](long T) { return (double)T / (double)(((T + 255) / 256) * 256); };
+    if (!no_big && !no_pp && K >= 2560 && (N % 256) == 0 && TPP >= 128 && 1.25 * round_eff(TPP) >= round_eff(T256)) {
+        // LONG K (the MLP's second GEMM, K = 4c): the 256x256 ping-pong tile, one tile per workgroup.  Its main loop sustains 1.3-1.5 PFLOP/s-equivalent per busy CU
+        // (8192x1280x5120 on 160 CUs: 917 TFLOP/s against 764 for the 256x128 tile; 32768x1280x5120, 2.5 rounds of the chip: 1050 against 989), but every tile pays a
+        // ramp of ~100 KB of operands per CU and an epilogue of 32 fragments per wave that nothing overlaps (one workgroup per CU): at K = 1280 it is 5-15 % BEHIND the
+        // 256x128 tile (32768x5120x1280: 820 against 862; 32768x1280x1280: 674 against 812), below 128 tiles it leaves half the chip idle (4096x1280x5120: 493 against 755),
+        // and N that is not a multiple of 256 wastes tile columns (131072x640x2560: 732 against 829).  Half as many tiles also quantise worse into rounds of 256: 320 tiles
+        // (16384x1280x5120, batch 128 at 32x32 tokens) fill 62 % of two rounds where 640 tiles of 256x128 fill 83 % of three -- measured -0.4 % per image in the model -- so
+        // the rule asks for 1.25 x the round efficiency of the 256x128 launch (the main-loop advantage).  profiles/r06_gemm_bf16_pingpong_tile.txt, r06_bf16_pingpong_rule_ab.txt
+        cfg = 37; G = TPP;
+    } else if (T256 >= 1024 && (K <= 768 || N < 512)) {
         // short K (level-0 MLP in: 131072x2560x640, the VQGAN's 384- / 192-wide blocks) or few tile columns: IN THE MODEL (bias + GELU + bf16 store + GRN statistics in
         // the epilogue; profiles/r05_gemm_by_shape_bf16_config3_rule_ab.txt) the epilogue is as long as the main loop, and four independent 64x64 workgroups per CU
         // overlap one's epilogue with another's main loop: 131072x2560x640 1 114 us against 1 293 (256x128, one tile per workgroup) and 1 576 (persistent ranges,

@@ -1197,6 +1197,10 @@ extern "C" int paella_test_gemm_bf16_ln(const unsigned short* A16, const float* 
     g.ln_stats = ln_stats; g.ln_nblk = K / 16; g.ln_eps = 1e-6f; g.ln_wsum = wsum.p;
     return launch_gemm_cfg(g, tile_cfg, splitk, ws, ws_bytes, (hipStream_t)stream);
 }
+// test hook (test_hooks.h): the fast mode's in-place GlobalResponseNorm apply on a bf16 tensor, h = bf16(h * scale[row / rows_per_sample] + shift)
+extern "C" int paella_test_grn_apply16(unsigned short* h, const float* scale, const float* shift, int64_t rows, int rows_per_sample, int C, void* stream) {
+    return launch_grn_apply16(h, scale, shift, rows, rows_per_sample, C, (hipStream_t)stream);
+}
 extern "C" int paella_op_layernorm(const float* x, float* y, int64_t rows, int C, float eps, void* stream) {
     return launch_layernorm(x, y, rows, C, eps, 1.f, 0.f, 0, 0, 0, (hipStream_t)stream);
 }

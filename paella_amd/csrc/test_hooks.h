@@ -9,7 +9,7 @@
 extern "C" {
 #endif
 /* one GEMM on bf16 operands (the opt-in fast mode's kernels: bit patterns A16 [M,K], W16 [N,K] supplied by the caller) with an explicit tile config
- * (10, 18, 19, 30..36; < 0 = heuristic) / workgroup count as paella_op_gemm; ln_stats != NULL: LayerNorm of the A rows folded into the epilogue from
+ * (10, 18, 19, 30..37; < 0 = heuristic) / workgroup count as paella_op_gemm; ln_stats != NULL: LayerNorm of the A rows folded into the epilogue from
  * [M, K/16, 2] (sum, centred M2) partials; C16 != NULL: also store the result rounded to bf16 (C may then be NULL) */
 int paella_test_gemm_bf16(const unsigned short* A16, const unsigned short* W16, const float* bias, const float* residual, float* C, unsigned short* C16,
                           int M, int N, int K, int act, const float* ln_stats, int tile_cfg, int splitk, void* ws, size_t ws_bytes, void* stream);
@@ -20,7 +20,10 @@ int paella_test_gemm_bf16_ln(const unsigned short* A16, const float* A32, const 
 /* the bf16 attention core of the opt-in fast mode (>= 256 queries in the model): q16 / ks16 / vs16 bf16 [B*L, nhead*D], conditioning k / v fp32, out16 bf16 */
 int paella_test_attention_bf16(const unsigned short* q16, const unsigned short* ks16, const unsigned short* vs16, const float* k_cond, const float* v_cond,
                                unsigned short* out16, int B, int nhead, int D, int Lq, int Lself, int Lcond, const float* key_weights, int n_kw, void* stream);
-/* A/B of the bf16 tile rules: bit 0 = never the 256x128 tile (the fp32 rules' tiles instead) */
+/* the fast mode's GlobalResponseNorm apply, in place on a bf16 tensor [rows, C]: h = bf16(h * scale[row / rows_per_sample][c] + shift[c]) (fp32 arithmetic, one rounding) */
+int paella_test_grn_apply16(unsigned short* h, const float* scale, const float* shift, int64_t rows, int rows_per_sample, int C, void* stream);
+/* A/B of the bf16 tile rules: bit 0 = never the 256x128 / 256x256 tiles (the fp32 rules' tiles instead), bit 1 = no persistent ranges of the 256x128 tile,
+ * bit 2 = never the 256x256 ping-pong tile (long-K launches take the 256x128 tile as in round 5) */
 int paella_test_gemm_bf16_rule(int mask);
 /* launches n_launches dependent, nearly empty kernels (blocks x 256 threads touching n_elems floats): boundary floor */
 int paella_test_launch_chain(float* buf, int n_elems, int blocks, int n_launches, void* stream);
@@ -28,9 +31,6 @@ int paella_test_launch_chain(float* buf, int n_elems, int blocks, int n_launches
  * 11 = its padded direct-to-LDS layout at every head_dim; 0 = default = direct-to-LDS staging, unpadded (4 workgroups per CU) at odd head_dim / 16, padded otherwise
  * (attention.hip: STG; bit-identical outputs; A/B probe tools/attn_probe.py) */
 int paella_test_attention_variant(int v);
-/* depthwise 3x3 + LayerNorm: 0 = always one workgroup per position, 1 = default (strips of 8 positions per workgroup from 4096 positions up), 2 = strips whenever
- * the strip kernel has an instantiation (<= 2048 channels, no skip input); bit-identical outputs (tests/test_gpu_ops.py) */
-int paella_test_dwconv_strip(int mode);
 /* C = prologue(A) . W^T with an explicit tile config / workgroup count (as paella_op_gemm): mode 1: a' = a * scale[row / rows_per_sample][k] +
  * shift[k] (the GRN apply of the MLP's second GEMM); mode 2: a' = (a - mean) * rstd from ln_stats [M, K/16, 2] = per 16-column block (sum, M2 =
  * sum of squared deviations from the block mean) (LayerNorm folded into the consumer's EPILOGUE; the hook sums W's rows itself with one extra M = 1 launch per call) */

@@ -132,6 +132,58 @@ def test_bf16_gemm_tiles_agree_bit_for_bit(built_lib, M, N, K):
         assert torch.equal(outs[tile], outs[base]), "bf16 tile %d differs from tile %d" % (tile, base)
 
 
+@pytest.mark.parametrize("B,rps,C", [(3, 64, 1024), (2, 256, 2560), (5, 16, 512), (2, 48, 5120), (3, 64, 1032), (1, 20, 640)])
+def test_grn_apply16_both_forms(built_lib, B, rps, C):
+    """The in-place GlobalResponseNorm apply of the fast mode, column-owning form (C % 512 == 0, rows per sample % 16 == 0) and grid-stride form (everything else):
+    bf16(h * scale[sample] + shift) with fp32 arithmetic and ONE rounding -- equal to the fp64 result rounded once, except where fp32 puts it on the other side of a bf16 tie."""
+    lib = built_lib
+    g = torch.Generator().manual_seed(B * rps + C)
+    h = torch.randn(B * rps, C, generator=g).bfloat16()
+    scale, shift = 1 + 0.5 * torch.randn(B, C, generator=g), torch.randn(C, generator=g)
+    hd, sd, td = h.to(DEV), scale.to(DEV), shift.to(DEV)
+    assert lib.paella_test_grn_apply16(_p(hd), _p(sd), _p(td), B * rps, rps, C, _st()) == 0, lib.paella_last_error()
+    ref = h.double().view(B, rps, C) * scale.double()[:, None, :] + shift.double()
+    got = hd.cpu().view(B, rps, C)
+    exact = ref.float().bfloat16()
+    diff = got != exact
+    # a mismatch must sit within fp32 rounding of a bf16 rounding boundary: |ref - midpoint| <= 2^-22 |ref|
+    if diff.any():
+        r = ref[diff]
+        lo, hi = torch.minimum(got[diff].double(), exact[diff].double()), torch.maximum(got[diff].double(), exact[diff].double())
+        assert torch.all((r - (lo + hi) / 2).abs() <= r.abs() * 2.0 ** -21 + 1e-30)
+    assert diff.float().mean().item() < 1e-3
+
+
+def test_bf16_launch_rule_takes_the_pingpong_tile_for_long_k(built_lib):
+    """The launch rule's long-K branch (K >= 2560, N % 256 == 0, >= 128 tiles of 256x256: the MLP's second GEMM at large batch) runs the ping-pong tile: with the
+    epilogue the model gives that launch (bias + residual + bf16 copy) the heuristic's output equals the explicit tile 37 AND the 64x64 tile bit for bit, on M that is
+    not a multiple of the tile; with the rule's bit 2 set it is the round-5 choice (same bits again)."""
+    lib = built_lib
+    M, N, K = 32768 - 40, 256, 2560
+    g = torch.Generator().manual_seed(77)
+    A16 = torch.randn(M, K, generator=g).bfloat16().to(DEV)
+    W16 = (torch.randn(N, K, generator=g) / 8).bfloat16().to(DEV)
+    bd, Rd = torch.randn(N, generator=g).to(DEV), torch.randn(M, N, generator=g).to(DEV)
+    ws = _lib.new_workspace(256 << 20, DEV)
+    outs = {}
+    try:
+        for name, tile, rule in [("rule", -1, 0), ("pp", 37, 0), ("t18", 18, 0), ("rule_no_pp", -1, 4)]:
+            lib.paella_test_gemm_bf16_rule(rule)
+            C = torch.full((M, N), float("nan"), device=DEV)
+            C16 = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+            rc = lib.paella_test_gemm_bf16(_p(A16), _p(W16), _p(bd), _p(Rd), _p(C), _p(C16), M, N, K, 0, None, tile, 1, _p(ws), ws.numel(), _st())
+            assert rc == 0, lib.paella_last_error()
+            outs[name] = (C, C16)
+    finally:
+        lib.paella_test_gemm_bf16_rule(0)
+    torch.cuda.synchronize()
+    for name in ("pp", "t18", "rule_no_pp"):
+        assert torch.equal(outs["rule"][0], outs[name][0]) and torch.equal(outs["rule"][1], outs[name][1]), name
+    ref = (A16[:512].cpu().double() @ W16.cpu().double().t() + bd.cpu().double() + Rd[:512].cpu().double()).float()
+    np.testing.assert_allclose(outs["rule"][0][:512].cpu().numpy(), ref.numpy(), atol=6e-3, rtol=3e-5)
+    assert torch.equal(outs["rule"][1], outs["rule"][0].bfloat16())
+
+
 def test_bf16_gemm_stream_k_is_repeatable(built_lib):
     lib = built_lib
     M, N, K = 96, 640, 2560

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Fast mode, same box: HEAD baseline copy (ab_base/) against the tree with the long-K ping-pong rule on / off (hook bit 2).
+out=gpurun_out/ab_bf16_final.txt
+: > $out
+run() {  # dir label args...
+  d=$1; shift; l=$1; shift
+  ( cd $d && python bench.py --no-cpu-baseline --no-extra --no-roofline "$@" 2>/dev/null | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('%-18s %-84s %9.3f ms/step  %8.3f img/s' % ('$l', ' '.join(sys.argv[1:]), d['ms_per_step'], d['value']))" "$@" ) >> $out
+}
+for rep in 1 2; do
+  for cfg in "--gemm bf16 --batch 64 --grid 64 --sample-steps 12 --steps 2 --warmup 1" "--gemm bf16 --batch 128 --steps 2 --warmup 1" "--gemm bf16 --batch 32 --steps 3 --warmup 1"; do
+    [ -d ab_base ] && run ab_base base $cfg
+    run . "new,no-pingpong" $cfg --hook gemm_bf16_rule=4
+    run . "new" $cfg
+  done
+done
+[ -d ab_base ] && run ab_base base --gemm bf16 --batch 1 --steps 20 --warmup 3
+run . new --gemm bf16 --batch 1 --steps 20 --warmup 3
+cat $out
