@@ -654,6 +654,39 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? ring_wg_per_cu(WM, WN, TM,
         }
     };
 
+    // Fused tail: the noise of a logit, log q = log(-log u) with u from Philox keyed by (seed, GLOBAL row, label quad, step), does not depend on the logit -- it is drawn
+    // AHEAD of the main loop, under the tile's first operand fetch (a head launch is one whole tile per workgroup), instead of in the epilogue: twenty 64-bit multiplies per
+    // label quad and two hardware logs per label, ~4 ms of VALU work per launch at configs[2] that used to follow the 7.3 ms of MFMAs.  Same counters, same arithmetic
+    // (philox.h: one definition for the fused and the unfused tail): identical tokens.
+    constexpr bool TAIL_AHEAD = TAIL && DMA;  // the product's head tiles (64x64 direct-to-LDS, fp32 and bf16); the A/B-only head tiles sit at their register limit and keep drawing per fragment in the epilogue
+    float tlq[TAIL_AHEAD ? TM * TN : 1][4];
+    int tlq_tile = -1;       // tile the drawn noise belongs to
+    int tail_cur_tile = -1;  // tile being finished (set by flush)
+    auto tail_draw = [&](int tile) __attribute__((always_inline)) {
+        if constexpr (TAIL_AHEAD) {
+            if (g.ft.mode != 1) {
+                const FusedTail& ft = g.ft;
+                int tile_m, tile_n;
+                sk_tile_coords<(BM >= 64)>(p, tile, tile_m, tile_n);
+                const uint64_t seed = ft.seed + (ft.seed_ptr ? *ft.seed_ptr : 0ull);
+                const int64_t row_off = ft.row_offset + (ft.row_offset_ptr ? *ft.row_offset_ptr : 0);
+                const int L4 = g.N >> 2;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int m = tile_m * BM + (wm * TM + i) * 16 + r16;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const int nn = tile_n * BN + (wn * TN + j) * 16 + kq * 4;
+                        uint32_t rb[4];
+                        philox4x32(seed, (uint64_t)(m + row_off) * L4 + (nn >> 2), ft.offset, rb);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) tlq[i * TN + j][e] = log_exp1(rb[e]);
+                    }
+                }
+                tlq_tile = tile;
+            }
+        }
+    };
     // ---- epilogue of a finished tile: lane holds out[m = ..+r16][n = ..+kq*4 .. +3] ----
     auto epilogue = [&](int m0, int n0, int r16, int kq) {
         if constexpr (TAIL) {
@@ -663,6 +696,7 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? ring_wg_per_cu(WM, WN, TM,
             const uint64_t seed = ft.seed + (ft.seed_ptr ? *ft.seed_ptr : 0ull);
             const int64_t row_off = ft.row_offset + (ft.row_offset_ptr ? *ft.row_offset_ptr : 0);
             const int L4 = g.N >> 2;
+            if (TAIL_AHEAD && tlq_tile != tail_cur_tile) tail_draw(tail_cur_tile);  // (never in the product: a head launch is one tile per workgroup and drew its noise under the first fetch)
             float* s_score = smem + FLAG_OFF + 16;
             int* s_idx = reinterpret_cast<int*>(s_score + BM * WN);
             const int tile_n_id = n0 / BN;
@@ -683,13 +717,21 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? ring_wg_per_cu(WM, WN, TM,
                             for (int e = 0; e < 4; ++e)
                                 if (v[e] > best) { best = v[e]; best_i = nn + e; }
                         } else {
-                            uint32_t rb[4];
-                            philox4x32(seed, (uint64_t)(m + row_off) * L4 + (nn >> 2), ft.offset, rb);
+                            float lq[4];
+                            if constexpr (TAIL_AHEAD) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) lq[e] = tlq[i * TN + j][e];  // (drawn ahead of the main loop: tail_draw)
+                            } else {
+                                uint32_t rb[4];
+                                philox4x32(seed, (uint64_t)(m + row_off) * L4 + (nn >> 2), ft.offset, rb);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) lq[e] = log_exp1(rb[e]);
+                            }
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 // labels are visited in increasing order inside a lane, so "first index wins ties" is a strict comparison here (one compare + two
                                 // selects per logit instead of the general rule's three compares); the cross-lane merges below keep the general rule
-                                const float sc = tail_score_gumbel(v[e], inv_t, log_exp1(rb[e]));
+                                const float sc = tail_score_gumbel(v[e], inv_t, lq[e]);
                                 if (sc > best) { best = sc; best_i = nn + e; }
                             }
                         }
@@ -888,6 +930,7 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? ring_wg_per_cu(WM, WN, TM,
                     }
             }
         }
+        tail_cur_tile = tile;
         if (finish) epilogue(tile_m * BM, tile_n * BN, r16, kq);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -1318,9 +1361,12 @@ __global__ __launch_bounds__(64 * WM * WN, RING > 0 ? ring_wg_per_cu(WM, WN, TM,
             }
         }
     };
+    const int tile_first = (int)fast_div(u0, p.dKT);
 #pragma unroll
     for (int j = 0; j < PD; ++j) fetch(R[j], 0);  // (DMA variants are 1-deep: unit 0 goes straight to LDS stage 0)
     ln_row_stats();  // while the first units are in flight
+    if constexpr (TAIL_AHEAD) tail_draw(tile_first);  // fused tail: the tile's noise, under the same latency (the product's head tiles; the A/B-only head tiles, at their register
+                                                       // limit, draw it in the epilogue as before -- same numbers either way)
     store_unit(R[0], 0);
     __syncthreads();
     if constexpr (PIPE) read_group(std::integral_constant<int, 0>{}, 0, (int)(u0 - fast_div(u0, p.dKT) * (unsigned)KT));
